@@ -1,0 +1,392 @@
+/*
+ * pq_oracle.c -- CPU ORACLE for the PQ/OPQ encode-reconstruct hot path.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  The product path (reductive_amd/ + libpqhip.so) never links,
+ * imports or calls anything in oracle/.
+ *
+ * It restates, in plain C, the algorithm of finalfusion/reductive v0.9.0
+ * (all citations relative to the reference tree):
+ *   src/pq/pq.rs:268-283       Pq::quantize_batch_into   (optional x.dot(P), then primitives)
+ *   src/pq/pq.rs:309-327       Pq::reconstruct_batch_into (gather, optional .dot(P^T))
+ *   src/pq/primitives.rs:64-104   quantize_batch_into     (loop over subquantizers)
+ *   src/pq/primitives.rs:110-173  reconstruct_into / reconstruct_batch_into
+ *   src/kmeans.rs:133-159      cluster_assignments        (distance matrix, first-minimum argmin)
+ *   src/kmeans.rs:111-126      cluster_assignment         (single-vector twin)
+ *   src/linalg.rs:150-180      SquaredEuclideanDistance Ix2 x Ix2
+ *   src/linalg.rs:118-148      SquaredEuclideanDistance Ix1 x Ix2
+ *
+ * PARITY STATUS.  The reference is Rust and cannot be compiled in this image
+ * (no rustc/cargo), so this restatement is pinned by the reference's own
+ * known-answer tests (tests/golden/reference_kats.json, transcribed DATA from
+ * pq.rs:378-407, kmeans.rs:382-395, linalg.rs:291-313).  Those KATs are exact
+ * under any summation order.  The floating-point ROUNDING ORDER and the
+ * tie-break on real-valued data are fixed by third-party crates that are not
+ * in /root/reference (ndarray 0.15 `dot` -> matrixmultiply 0.3 sgemm;
+ * ordered-float 2; core::iter::Iterator::min_by_key) -- for those aspects
+ * parity is UNPINNED by the reference's tests and this file DECLARES the
+ * canonical arithmetic "CANON-F32" below, restating those crates' published
+ * algorithms.
+ *
+ * CANON-F32 (what libpqhip.so must match bit-for-bit for codes):
+ *  (1) squared norms  x.x and c.c : ndarray numeric_util::unrolled_dot --
+ *      eight partial sums p[l] += x[8t+l]*y[8t+l] (separately rounded multiply
+ *      and add, no FMA), then s = 0; s += (p0+p4); s += (p1+p5); s += (p2+p6);
+ *      s += (p3+p7); then the <8 tail elements s += x*y in order.
+ *  (2) dot products of the distance GEMM and of the rotation GEMM:
+ *      matrixmultiply's FMA micro-kernel -- every output element is ONE
+ *      sequential fmaf chain over k starting from +0, restarted every
+ *      KC = 256 values of k; blocks after the first are added to the running
+ *      output with one rounded add:  C = fl(C + chain_b).
+ *  (3) distance  D[i][j] = fl( fl(xx_i + cc_j) - fl(dp + dp) )   (linalg.rs:173-174)
+ *  (4) assignment = FIRST index of the minimum under ordered-float's total
+ *      order (NaN greater than everything, NaN == NaN, -0 == +0)
+ *      (kmeans.rs:149-156; Iterator::min_by_key keeps the first of equal minima).
+ *  (5) codes: `usize as u8` (primitives.rs:98-100); K <= 256 so no wrap here.
+ *  (6) reconstruction: exact copy of codebook rows (primitives.rs:141-147);
+ *      OPQ un-rotation r.dot(P^T) by rule (2).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PQO_KC 256 /* matrixmultiply sgemm k-block */
+
+#if defined(__x86_64__)
+#define PQO_CLONES __attribute__((target_clones("arch=haswell", "default")))
+#else
+#define PQO_CLONES
+#endif
+
+/* ---- (1) ndarray unrolled_dot ------------------------------------------------ */
+float pqo_dot_unrolled(const float *x, const float *y, int64_t n)
+{
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t i = 0;
+    while (n - i >= 8) {
+        for (int l = 0; l < 8; ++l) {
+            float prod = x[i + l] * y[i + l];
+            p[l] = p[l] + prod;
+        }
+        i += 8;
+    }
+    float sum = 0.0f;
+    sum = sum + (p[0] + p[4]);
+    sum = sum + (p[1] + p[5]);
+    sum = sum + (p[2] + p[6]);
+    sum = sum + (p[3] + p[7]);
+    for (; i < n; ++i) {
+        float prod = x[i] * y[i];
+        sum = sum + prod;
+    }
+    return sum;
+}
+
+/* ---- (4) ordered-float comparison ---------------------------------------------- */
+static inline int of_less(float a, float b)
+{
+    if (isnan(a)) return 0;
+    if (isnan(b)) return 1;
+    return a < b;
+}
+
+int64_t pqo_first_min(const float *d, int64_t n)
+{
+    int64_t best = 0;
+    for (int64_t j = 1; j < n; ++j)
+        if (of_less(d[j], d[best])) best = j;
+    return best;
+}
+
+/* ---- linalg.rs:150-180, literal (small inputs; used by the KAT tests) ---------- */
+/* x: [n, dd] row stride x_rs (unit column stride); c: [k, dd] contiguous; out [n,k] */
+void pqo_sqdist_mm(const float *x, int64_t n, int64_t x_rs, const float *c, int64_t k,
+                   int64_t dd, float *out)
+{
+    float *cc = (float *)malloc(sizeof(float) * (size_t)(k > 0 ? k : 1));
+    for (int64_t j = 0; j < k; ++j) cc[j] = pqo_dot_unrolled(c + j * dd, c + j * dd, dd);
+    for (int64_t i = 0; i < n; ++i) {
+        const float *xi = x + i * x_rs;
+        float xx = pqo_dot_unrolled(xi, xi, dd);
+        for (int64_t j = 0; j < k; ++j) {
+            float total = 0.0f;
+            for (int64_t kb = 0; kb < dd; kb += PQO_KC) {
+                int64_t ke = kb + PQO_KC < dd ? kb + PQO_KC : dd;
+                float ab = 0.0f;
+                for (int64_t q = kb; q < ke; ++q) ab = __builtin_fmaf(xi[q], c[j * dd + q], ab);
+                total = (kb == 0) ? ab : total + ab;
+            }
+            float t = xx + cc[j];
+            float u = total + total;
+            out[i * k + j] = t - u;
+        }
+    }
+    free(cc);
+}
+
+/* kmeans.rs:133-159 (Axis(0) instances) */
+void pqo_cluster_assignments(const float *centroids, int64_t k, int64_t dd, const float *x,
+                             int64_t n, int64_t x_rs, int64_t *out)
+{
+    float *d = (float *)malloc(sizeof(float) * (size_t)(k > 0 ? k : 1));
+    for (int64_t i = 0; i < n; ++i) {
+        pqo_sqdist_mm(x + i * x_rs, 1, x_rs, centroids, k, dd, d);
+        out[i] = pqo_first_min(d, k);
+    }
+    free(d);
+}
+
+/* ---- rotation  rx = x.dot(P)   (pq.rs:276) -------------------------------------- */
+/* one row; P is [d,d] row-major (rx[c] = sum_k x[k] P[k][c]); scratch ab[d] */
+PQO_CLONES
+static void rotate_row(const float *x, const float *P, int64_t d, float *out, float *ab)
+{
+    for (int64_t kb = 0; kb < d; kb += PQO_KC) {
+        int64_t ke = kb + PQO_KC < d ? kb + PQO_KC : d;
+        for (int64_t c = 0; c < d; ++c) ab[c] = 0.0f;
+        for (int64_t k = kb; k < ke; ++k) {
+            const float xv = x[k];
+            const float *Pk = P + k * d;
+            for (int64_t c = 0; c < d; ++c) ab[c] = __builtin_fmaf(xv, Pk[c], ab[c]);
+        }
+        if (kb == 0)
+            for (int64_t c = 0; c < d; ++c) out[c] = ab[c];
+        else
+            for (int64_t c = 0; c < d; ++c) out[c] = out[c] + ab[c];
+    }
+}
+
+/* x [n,d] strided (elements), out [n,d] contiguous */
+void pqo_rotate(const float *x, int64_t n, int64_t d, int64_t x_rs, int64_t x_cs, const float *P,
+                float *out)
+{
+    float *row = (float *)malloc(sizeof(float) * (size_t)d * 2);
+    float *ab = row + d;
+    for (int64_t i = 0; i < n; ++i) {
+        for (int64_t k = 0; k < d; ++k) row[k] = x[i * x_rs + k * x_cs];
+        rotate_row(row, P, d, out + i * d, ab);
+    }
+    free(row);
+}
+
+/* ---- encode ---------------------------------------------------------------------- */
+typedef struct {
+    int64_t M, K, dsub;
+    float *ct; /* [M][dsub][K]  transposed centroids  */
+    float *cc; /* [M][K]        squared norms (linalg.rs:168) */
+} enc_tables;
+
+static void build_tables(enc_tables *t, const float *cb, int64_t M, int64_t K, int64_t dsub)
+{
+    t->M = M; t->K = K; t->dsub = dsub;
+    t->ct = (float *)malloc(sizeof(float) * (size_t)(M * dsub * K));
+    t->cc = (float *)malloc(sizeof(float) * (size_t)(M * K));
+    for (int64_t m = 0; m < M; ++m)
+        for (int64_t j = 0; j < K; ++j) {
+            const float *c = cb + (m * K + j) * dsub;
+            t->cc[m * K + j] = pqo_dot_unrolled(c, c, dsub);
+            for (int64_t k = 0; k < dsub; ++k) t->ct[(m * dsub + k) * K + j] = c[k];
+        }
+}
+
+static void free_tables(enc_tables *t) { free(t->ct); free(t->cc); }
+
+/* one (already rotated, contiguous) row -> M codes (as int64 so any index width fits) */
+PQO_CLONES
+static void encode_row(const enc_tables *t, const float *row, float *acc, int64_t *codes)
+{
+    const int64_t K = t->K, dsub = t->dsub;
+    for (int64_t m = 0; m < t->M; ++m) {
+        const float *xs = row + m * dsub;
+        const float xx = pqo_dot_unrolled(xs, xs, dsub);
+        const float *cc = t->cc + m * K;
+        /* (2) one fmaf chain per centroid, k ascending, restart every KC */
+        for (int64_t kb = 0; kb < dsub; kb += PQO_KC) {
+            int64_t ke = kb + PQO_KC < dsub ? kb + PQO_KC : dsub;
+            float *ab = (kb == 0) ? acc : acc + K;
+            for (int64_t j = 0; j < K; ++j) ab[j] = 0.0f;
+            for (int64_t k = kb; k < ke; ++k) {
+                const float xv = xs[k];
+                const float *ctk = t->ct + (m * dsub + k) * K;
+                for (int64_t j = 0; j < K; ++j) ab[j] = __builtin_fmaf(xv, ctk[j], ab[j]);
+            }
+            if (kb != 0)
+                for (int64_t j = 0; j < K; ++j) acc[j] = acc[j] + ab[j];
+        }
+        /* (3) combine */
+        int any_nan = 0;
+        for (int64_t j = 0; j < K; ++j) {
+            float tt = xx + cc[j];
+            float u = acc[j] + acc[j];
+            float dj = tt - u;
+            acc[j] = dj;
+            any_nan |= (dj != dj);
+        }
+        /* (4) first minimum */
+        int64_t best = 0;
+        if (any_nan) {
+            best = pqo_first_min(acc, K);
+        } else {
+            float bv = acc[0];
+            for (int64_t j = 1; j < K; ++j)
+                if (acc[j] < bv) { bv = acc[j]; best = j; }
+        }
+        codes[m] = best;
+    }
+}
+
+typedef struct {
+    const enc_tables *t;
+    const float *P; /* or NULL */
+    const float *x;
+    int64_t x_rs, x_cs;
+    int64_t row_begin, row_end;
+    void *out;
+    int out_width; /* bytes: 1, 2, 4, 8 */
+    int64_t o_rs, o_cs;
+} enc_job;
+
+static void *encode_range(void *arg)
+{
+    enc_job *j = (enc_job *)arg;
+    const enc_tables *t = j->t;
+    const int64_t d = t->M * t->dsub;
+    float *buf = (float *)malloc(sizeof(float) * (size_t)(3 * d + 2 * t->K));
+    float *row = buf, *rrow = buf + d, *ab = buf + 2 * d, *acc = buf + 3 * d;
+    int64_t *codes = (int64_t *)malloc(sizeof(int64_t) * (size_t)t->M);
+    for (int64_t i = j->row_begin; i < j->row_end; ++i) {
+        for (int64_t k = 0; k < d; ++k) row[k] = j->x[i * j->x_rs + k * j->x_cs];
+        const float *src = row;
+        if (j->P) { rotate_row(row, j->P, d, rrow, ab); src = rrow; }
+        encode_row(t, src, acc, codes);
+        for (int64_t m = 0; m < t->M; ++m) {
+            int64_t off = i * j->o_rs + m * j->o_cs;
+            switch (j->out_width) {
+            case 1: ((uint8_t *)j->out)[off] = (uint8_t)codes[m]; break;
+            case 2: ((uint16_t *)j->out)[off] = (uint16_t)codes[m]; break;
+            case 4: ((uint32_t *)j->out)[off] = (uint32_t)codes[m]; break;
+            default: ((uint64_t *)j->out)[off] = (uint64_t)codes[m]; break;
+            }
+        }
+    }
+    free(codes);
+    free(buf);
+    return NULL;
+}
+
+/* Pq::quantize_batch_into.  cb: [M][K][dsub] C-order; P: [d][d] row-major or NULL;
+ * x: [n,d] with element strides; out: [n,M] of out_width-byte unsigned ints with element strides.
+ * n_threads <= 1 is the reference's own threading (its encode loop is single-threaded,
+ * primitives.rs:89-103); n_threads > 1 shards rows over pthreads (same arithmetic per row). */
+int pqo_quantize_batch(const float *cb, int64_t M, int64_t K, int64_t dsub, const float *P,
+                       const float *x, int64_t n, int64_t x_rs, int64_t x_cs, void *out,
+                       int out_width, int64_t o_rs, int64_t o_cs, int n_threads)
+{
+    if (M <= 0 || K <= 0 || dsub <= 0 || n < 0) return 1;
+    if (out_width != 1 && out_width != 2 && out_width != 4 && out_width != 8) return 1;
+    enc_tables t;
+    build_tables(&t, cb, M, K, dsub);
+    if (n_threads < 1) n_threads = 1;
+    if ((int64_t)n_threads > n) n_threads = n > 0 ? (int)n : 1;
+    enc_job *jobs = (enc_job *)malloc(sizeof(enc_job) * (size_t)n_threads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    int64_t per = (n + n_threads - 1) / n_threads;
+    for (int i = 0; i < n_threads; ++i) {
+        int64_t b = i * per, e = b + per;
+        if (b > n) b = n;
+        if (e > n) e = n;
+        jobs[i] = (enc_job){&t, P, x, x_rs, x_cs, b, e, out, out_width, o_rs, o_cs};
+    }
+    if (n_threads == 1) {
+        encode_range(&jobs[0]);
+    } else {
+        for (int i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, encode_range, &jobs[i]);
+        for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
+    }
+    free(th);
+    free(jobs);
+    free_tables(&t);
+    return 0;
+}
+
+/* ---- reconstruct ------------------------------------------------------------------ */
+/* Pq::reconstruct_batch_into.  codes [n,M] (code_width-byte unsigned, element strides);
+ * out [n,d] f32 with element strides.  Returns 2 if a code >= K (reference: index_axis panic,
+ * primitives.rs:146). */
+int pqo_reconstruct_batch(const float *cb, int64_t M, int64_t K, int64_t dsub, const float *P,
+                          const void *codes, int code_width, int64_t n, int64_t c_rs,
+                          int64_t c_cs, float *out, int64_t o_rs, int64_t o_cs)
+{
+    const int64_t d = M * dsub;
+    float *row = (float *)malloc(sizeof(float) * (size_t)d * 3);
+    float *rrow = row + d, *ab = row + 2 * d;
+    float *PT = NULL;
+    if (P) { /* r.dot(P^T): out[k] = sum_c r[c] * P[k][c]  == rotate_row with P^T */
+        PT = (float *)malloc(sizeof(float) * (size_t)(d * d));
+        for (int64_t k = 0; k < d; ++k)
+            for (int64_t c = 0; c < d; ++c) PT[c * d + k] = P[k * d + c];
+    }
+    int rc = 0;
+    for (int64_t i = 0; i < n && !rc; ++i) {
+        for (int64_t m = 0; m < M; ++m) {
+            int64_t off = i * c_rs + m * c_cs;
+            uint64_t code;
+            switch (code_width) {
+            case 1: code = ((const uint8_t *)codes)[off]; break;
+            case 2: code = ((const uint16_t *)codes)[off]; break;
+            case 4: code = ((const uint32_t *)codes)[off]; break;
+            default: code = ((const uint64_t *)codes)[off]; break;
+            }
+            if (code >= (uint64_t)K) { rc = 2; break; }
+            memcpy(row + m * dsub, cb + (m * K + (int64_t)code) * dsub, sizeof(float) * (size_t)dsub);
+        }
+        if (rc) break;
+        const float *src = row;
+        if (PT) { rotate_row(row, PT, d, rrow, ab); src = rrow; }
+        for (int64_t k = 0; k < d; ++k) out[i * o_rs + k * o_cs] = src[k];
+    }
+    free(PT);
+    free(row);
+    return rc;
+}
+
+/* ---- single-vector twins (kept on the CPU by the product too) ---------------------- */
+/* linalg.rs:118-148: dp_j = centroid_j.dot(x) is a 1-D x 1-D ndarray dot = unrolled_dot. */
+int pqo_quantize_vector(const float *cb, int64_t M, int64_t K, int64_t dsub, const float *P,
+                        const float *x, int64_t *codes)
+{
+    const int64_t d = M * dsub;
+    float *rx = (float *)malloc(sizeof(float) * (size_t)(d + K));
+    float *dist = rx + d;
+    if (P) {
+        /* x.dot(P) for a 1-D x: ndarray's non-BLAS gemv is, per output c, a dot of x with the
+         * strided column P[:,c] -> the plain sequential loop  s = s + a*b. */
+        for (int64_t c = 0; c < d; ++c) {
+            float s = 0.0f;
+            for (int64_t k = 0; k < d; ++k) { float prod = x[k] * P[k * d + c]; s = s + prod; }
+            rx[c] = s;
+        }
+    } else {
+        memcpy(rx, x, sizeof(float) * (size_t)d);
+    }
+    for (int64_t m = 0; m < M; ++m) {
+        const float *xs = rx + m * dsub;
+        float xx = pqo_dot_unrolled(xs, xs, dsub);
+        for (int64_t j = 0; j < K; ++j) {
+            const float *c = cb + (m * K + j) * dsub;
+            float cc = pqo_dot_unrolled(c, c, dsub);
+            float dp = pqo_dot_unrolled(c, xs, dsub);
+            float t = xx + cc;
+            float u = dp + dp;
+            dist[j] = t - u;
+        }
+        codes[m] = pqo_first_min(dist, K);
+    }
+    free(rx);
+    return 0;
+}
+
+int pqo_abi_version(void) { return 1; }

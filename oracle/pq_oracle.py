@@ -1,0 +1,150 @@
+"""ctypes loader for the CPU oracle (oracle/pq_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under reductive_amd/ may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpq_oracle.so")
+_lib = None
+
+_i64 = ctypes.c_int64
+_fp = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pq_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.pqo_dot_unrolled.restype = ctypes.c_float
+        L.pqo_dot_unrolled.argtypes = [_fp, _fp, _i64]
+        L.pqo_first_min.restype = _i64
+        L.pqo_first_min.argtypes = [_fp, _i64]
+        L.pqo_sqdist_mm.restype = None
+        L.pqo_sqdist_mm.argtypes = [_fp, _i64, _i64, _fp, _i64, _i64, _fp]
+        L.pqo_cluster_assignments.restype = None
+        L.pqo_cluster_assignments.argtypes = [_fp, _i64, _i64, _fp, _i64, _i64,
+                                              ctypes.POINTER(_i64)]
+        L.pqo_rotate.restype = None
+        L.pqo_rotate.argtypes = [_fp, _i64, _i64, _i64, _i64, _fp, _fp]
+        L.pqo_quantize_batch.restype = ctypes.c_int
+        L.pqo_quantize_batch.argtypes = [_fp, _i64, _i64, _i64, _fp, _fp, _i64, _i64, _i64, _vp,
+                                         ctypes.c_int, _i64, _i64, ctypes.c_int]
+        L.pqo_reconstruct_batch.restype = ctypes.c_int
+        L.pqo_reconstruct_batch.argtypes = [_fp, _i64, _i64, _i64, _fp, _vp, ctypes.c_int, _i64,
+                                            _i64, _i64, _fp, _i64, _i64]
+        L.pqo_quantize_vector.restype = ctypes.c_int
+        L.pqo_quantize_vector.argtypes = [_fp, _i64, _i64, _i64, _fp, _fp, ctypes.POINTER(_i64)]
+        _lib = L
+    return _lib
+
+
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_fp) if a is not None else None
+
+
+def _estrides(a):
+    assert all(s % a.itemsize == 0 for s in a.strides)
+    return [s // a.itemsize for s in a.strides]
+
+
+def dot_unrolled(x, y):
+    x, y = _f32c(x), _f32c(y)
+    return np.float32(lib().pqo_dot_unrolled(_p(x), _p(y), x.size))
+
+
+def first_min(d):
+    d = _f32c(d)
+    return int(lib().pqo_first_min(_p(d), d.size))
+
+
+def sqdist(x, c):
+    """linalg.rs:150-180 for row-contiguous x [n,dd] and c [k,dd] -> [n,k]."""
+    x, c = _f32c(x), _f32c(c)
+    out = np.empty((x.shape[0], c.shape[0]), np.float32)
+    lib().pqo_sqdist_mm(_p(x), x.shape[0], x.shape[1], _p(c), c.shape[0], c.shape[1], _p(out))
+    return out
+
+
+def cluster_assignments(centroids, x):
+    centroids, x = _f32c(centroids), _f32c(x)
+    out = np.empty(x.shape[0], np.int64)
+    lib().pqo_cluster_assignments(_p(centroids), centroids.shape[0], centroids.shape[1], _p(x),
+                                  x.shape[0], x.shape[1], out.ctypes.data_as(ctypes.POINTER(_i64)))
+    return out
+
+
+def rotate(x, P):
+    x = np.asarray(x, dtype=np.float32)
+    P = _f32c(P)
+    rs, cs = _estrides(x)
+    out = np.empty(x.shape, np.float32)
+    lib().pqo_rotate(_p(x), x.shape[0], x.shape[1], rs, cs, _p(P), _p(out))
+    return out
+
+
+def quantize_batch(quantizers, x, projection=None, dtype=np.uint8, n_threads=1, out=None):
+    """Pq::quantize_batch (pq.rs:256-283).  quantizers [M,K,dsub]; x [n,d] any strides."""
+    q = _f32c(quantizers)
+    M, K, dsub = q.shape
+    x = np.asarray(x, dtype=np.float32)
+    assert x.ndim == 2 and x.shape[1] == M * dsub, "Quantizer and vector length mismatch"
+    P = _f32c(projection) if projection is not None else None
+    if out is None:
+        out = np.zeros((x.shape[0], M), dtype=dtype)
+    assert out.shape == (x.shape[0], M)
+    rs, cs = _estrides(x) if x.size else (x.shape[1], 1)
+    ors, ocs = _estrides(out) if out.size else (M, 1)
+    rc = lib().pqo_quantize_batch(_p(q), M, K, dsub, _p(P), _p(x), x.shape[0], rs, cs,
+                                  out.ctypes.data_as(_vp), out.itemsize, ors, ocs, n_threads)
+    assert rc == 0, rc
+    return out
+
+
+def reconstruct_batch(quantizers, codes, projection=None):
+    """Reconstruct::reconstruct_batch (traits.rs:109-117 -> pq.rs:309-327)."""
+    q = _f32c(quantizers)
+    M, K, dsub = q.shape
+    codes = np.asarray(codes)
+    assert codes.ndim == 2 and codes.shape[1] == M
+    assert codes.dtype.kind == "u" or codes.dtype.kind == "i"
+    P = _f32c(projection) if projection is not None else None
+    out = np.zeros((codes.shape[0], M * dsub), np.float32)
+    crs, ccs = _estrides(codes) if codes.size else (M, 1)
+    rc = lib().pqo_reconstruct_batch(_p(q), M, K, dsub, _p(P), codes.ctypes.data_as(_vp),
+                                     codes.itemsize, codes.shape[0], crs, ccs, _p(out),
+                                     M * dsub, 1)
+    if rc == 2:
+        raise IndexError("code >= K (reference: ndarray index_axis panic, primitives.rs:146)")
+    assert rc == 0, rc
+    return out
+
+
+def quantize_vector(quantizers, x, projection=None):
+    q = _f32c(quantizers)
+    M, K, dsub = q.shape
+    x = _f32c(x)
+    assert x.shape == (M * dsub,), "Quantizer and vector length mismatch"
+    P = _f32c(projection) if projection is not None else None
+    out = np.empty(M, np.int64)
+    lib().pqo_quantize_vector(_p(q), M, K, dsub, _p(P), _p(x),
+                              out.ctypes.data_as(ctypes.POINTER(_i64)))
+    return out

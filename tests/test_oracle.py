@@ -1,0 +1,193 @@
+"""CPU tests: pin oracle/pq_oracle.c against the reference's own KATs and against an
+independent exact-rational model of CANON-F32 (tests/exact_f32.py)."""
+import numpy as np
+import pytest
+
+import exact_f32 as ex
+import synth
+from oracle import pq_oracle as orc
+
+
+# ---- reference KATs (tests/golden/reference_kats.json) -----------------------------------
+def test_kat_pq_quantize_batch(kats):
+    k = kats["pq_predefined_codebook"]
+    q = np.array(k["quantizers"], np.float32)
+    x = np.array(k["vectors"], np.float32)
+    for dt in (np.uint8, np.uint16, np.uint32, np.uint64):
+        codes = orc.quantize_batch(q, x, dtype=dt)
+        assert codes.dtype == dt
+        assert codes.tolist() == k["quantizations"]
+
+
+def test_kat_pq_quantize_vector(kats):
+    k = kats["pq_predefined_codebook"]
+    q = np.array(k["quantizers"], np.float32)
+    for v, want in zip(k["vectors"], k["quantizations"]):
+        assert orc.quantize_vector(q, np.array(v, np.float32)).tolist() == want
+
+
+def test_kat_pq_reconstruct(kats):
+    k = kats["pq_predefined_codebook"]
+    q = np.array(k["quantizers"], np.float32)
+    codes = np.array(k["quantizations"], np.uint64)
+    rec = orc.reconstruct_batch(q, codes)
+    assert rec.tolist() == k["reconstructions"]
+    rec8 = orc.reconstruct_batch(q, codes.astype(np.uint8))
+    assert rec8.tolist() == k["reconstructions"]
+    assert q.shape[0] == k["quantized_len"] and q.shape[0] * q.shape[2] == k["reconstructed_len"]
+
+
+def test_kat_cluster_assignments(kats):
+    k = kats["cluster_assignments"]
+    c = np.array(k["centroids"], np.float32)
+    x = np.array(k["instances"], np.float32)
+    assert orc.cluster_assignments(c, x).tolist() == k["assignments"]
+    # transposed storage of the same instances (kmeans.rs:397-399): same answer
+    xt = np.asfortranarray(x)
+    assert orc.quantize_batch(c[None], xt, dtype=np.uint64)[:, 0].tolist() == k["assignments"]
+
+
+def test_kat_squared_distance(kats):
+    k = kats["squared_euclidean_distance"]
+    a, b = k["ix2_ix2"]["a"], k["ix2_ix2"]["b"]
+    assert orc.sqdist(np.array(a), np.array(b)).tolist() == k["ix2_ix2"]["expected"]
+    a1 = np.array([k["ix1_ix2"]["a"]])
+    assert orc.sqdist(a1, np.array(k["ix1_ix2"]["b"]))[0].tolist() == k["ix1_ix2"]["expected"]
+    a0, b0 = np.array([k["ix1_ix1"]["a"]]), np.array([k["ix1_ix1"]["b"]])
+    assert orc.sqdist(a0, b0)[0, 0] == k["ix1_ix1"]["expected"]
+
+
+def test_kat_index_width(kats):
+    k = kats["index_width"]
+    q = synth.uniform01(1, (1, k["k_ok_u8"], k["dsub"]))
+    x = synth.uniform01(2, (3, k["dsub"]))
+    codes = orc.quantize_batch(q, x)           # K=256 fits u8
+    assert codes.dtype == np.uint8 and codes.shape == (3, 1)
+
+
+# ---- exact-rational cross-check of the declared arithmetic --------------------------------
+@pytest.mark.parametrize("n", [1, 3, 7, 8, 9, 16, 20, 23, 31])
+def test_dot_unrolled_matches_exact(n):
+    x = synth.normalish(10 + n, (n,))
+    y = synth.normalish(50 + n, (n,))
+    assert float(orc.dot_unrolled(x, y)) == ex.dot_unrolled(list(x), list(y))
+
+
+@pytest.mark.parametrize("shape", [(5, 2, 4, 20), (4, 3, 8, 16), (3, 5, 5, 3), (2, 1, 3, 7)])
+def test_quantize_matches_exact(shape):
+    n, M, K, dsub = shape
+    q = synth.normalish(3, (M, K, dsub))
+    x = synth.normalish(4, (n, M * dsub))
+    assert orc.quantize_batch(q, x, dtype=np.uint64).tolist() == ex.quantize_batch(q, x).tolist()
+    d_c = orc.sqdist(x[:, :dsub], q[0])
+    d_e = ex.sqdist(x[:, :dsub], q[0])
+    assert d_c.tobytes() == d_e.tobytes()
+
+
+def test_rotation_kc_split_matches_exact():
+    d = 260                                     # > KC=256 -> two k-blocks
+    x = synth.normalish(5, (2, d))
+    P = synth.normalish(6, (d, d))[:, :]        # arbitrary matrix is enough for the arithmetic
+    got = orc.rotate(x, P)
+    want = ex.rotate(x, P)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_opq_quantize_reconstruct_matches_exact():
+    M, K, dsub = 2, 4, 3
+    d = M * dsub
+    q = synth.normalish(7, (M, K, dsub))
+    x = synth.normalish(8, (4, d))
+    P = synth.orthonormal(9, d)
+    codes = orc.quantize_batch(q, x, projection=P, dtype=np.uint64)
+    assert codes.tolist() == ex.quantize_batch(q, x, projection=P).tolist()
+    rec = orc.reconstruct_batch(q, codes, projection=P)
+    assert rec.tobytes() == ex.reconstruct_batch(q, codes, projection=P).tobytes()
+
+
+# ---- tie-break / special values (not pinned by the reference's tests; declared) -----------
+def test_exact_tie_lowest_index_wins():
+    q = np.zeros((1, 6, 4), np.float32)
+    q[0, 1] = q[0, 4] = [1, 2, 3, 4]            # duplicates: 1 and 4
+    q[0, 2] = q[0, 3] = [9, 9, 9, 9]
+    q[0, 0] = [5, 5, 5, 5]
+    q[0, 5] = [-1, 0, 0, 0]
+    x = np.array([[1, 2, 3, 4], [9, 9, 9, 9], [0, 0, 0, 0]], np.float32)
+    assert orc.quantize_batch(q, x)[:, 0].tolist() == [1, 2, 5]
+
+
+def test_nan_and_inf_rows():
+    q = synth.normalish(11, (2, 8, 4))
+    x = synth.normalish(12, (5, 8))
+    x[0, 0] = np.nan                            # whole first sub-row distance is NaN -> index 0
+    x[1, 5] = np.inf                            # xx = inf, dp = +-inf -> NaN or +inf per centroid
+    x[2, :] = 0
+    codes = orc.quantize_batch(q, x)
+    assert codes[0, 0] == 0                     # all-NaN row of distances -> index 0
+    assert codes.tolist() == ex.quantize_batch(q, x).tolist()
+    # a NaN centroid is never chosen while a finite distance exists
+    q2 = q.copy()
+    q2[0, 0, 0] = np.nan
+    c2 = orc.quantize_batch(q2, x[2:])
+    assert (c2[:, 0] != 0).all()
+    assert c2.tolist() == ex.quantize_batch(q2, x[2:]).tolist()
+
+
+def test_first_min_total_order():
+    nan = float("nan")
+    assert orc.first_min(np.array([nan, nan], np.float32)) == 0
+    assert orc.first_min(np.array([nan, 3, 1, 1], np.float32)) == 2
+    assert orc.first_min(np.array([0.0, -0.0], np.float32)) == 0
+    assert orc.first_min(np.array([np.inf, np.inf, -np.inf], np.float32)) == 2
+
+
+def test_large_norm_rows_create_ties():
+    # |x|^2 >> |c|^2: xx + cc rounds identically for many centroids -> rounding ties.
+    q = synth.normalish(13, (1, 16, 4)) * np.float32(1e-3)
+    x = synth.normalish(14, (6, 4)) * np.float32(1e4)
+    assert orc.quantize_batch(q, x, dtype=np.uint64).tolist() == ex.quantize_batch(q, x).tolist()
+
+
+def test_strided_inputs_and_outputs():
+    q = synth.normalish(15, (3, 8, 4))
+    big = synth.normalish(16, (10, 40))
+    x = big[::2, 5:17]                          # row stride 80, unit col stride, offset
+    want = orc.quantize_batch(q, np.ascontiguousarray(x))
+    assert orc.quantize_batch(q, x).tolist() == want.tolist()
+    assert orc.quantize_batch(q, np.asfortranarray(x)).tolist() == want.tolist()
+    out = np.zeros((3, 5), np.uint8).T          # transposed output buffer
+    orc.quantize_batch(q, x, out=out)
+    assert out.tolist() == want.tolist()
+
+
+def test_multithreaded_oracle_is_identical():
+    q = synth.normalish(17, (15, 256, 20))
+    x = synth.normalish(18, (257, 300))
+    a = orc.quantize_batch(q, x, n_threads=1)
+    b = orc.quantize_batch(q, x, n_threads=5)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_reconstruct_rejects_out_of_range_code():
+    q = synth.normalish(19, (2, 5, 3))
+    with pytest.raises(IndexError):
+        orc.reconstruct_batch(q, np.array([[0, 5]], np.uint8))
+
+
+def test_empty_batch():
+    q = synth.normalish(20, (2, 4, 3))
+    assert orc.quantize_batch(q, np.zeros((0, 6), np.float32)).shape == (0, 2)
+    assert orc.reconstruct_batch(q, np.zeros((0, 2), np.uint8)).shape == (0, 6)
+
+
+def test_brute_force_f64_agrees_when_gap_is_clear():
+    # independent formulation: argmin ||x-c||^2 in float64 wherever the gap is far above fp32 noise
+    q = synth.normalish(21, (15, 256, 20))
+    x = synth.normalish(22, (64, 300))
+    codes = orc.quantize_batch(q, x)
+    xs = x.reshape(64, 15, 20).astype(np.float64)
+    d = ((xs[:, :, None, :] - q[None].astype(np.float64)) ** 2).sum(-1)      # [n, M, K]
+    srt = np.sort(d, axis=-1)
+    clear = (srt[..., 1] - srt[..., 0]) > 1e-3
+    assert clear.mean() > 0.9
+    assert (d.argmin(-1)[clear] == codes[clear]).all()
