@@ -55,12 +55,6 @@
 
 #define PQO_KC 256 /* matrixmultiply sgemm k-block */
 
-#if defined(__x86_64__)
-#define PQO_CLONES __attribute__((target_clones("arch=haswell", "default")))
-#else
-#define PQO_CLONES
-#endif
-
 /* ---- (1) ndarray unrolled_dot ------------------------------------------------ */
 float pqo_dot_unrolled(const float *x, const float *y, int64_t n)
 {
@@ -140,24 +134,7 @@ void pqo_cluster_assignments(const float *centroids, int64_t k, int64_t dd, cons
 }
 
 /* ---- rotation  rx = x.dot(P)   (pq.rs:276) -------------------------------------- */
-/* one row; P is [d,d] row-major (rx[c] = sum_k x[k] P[k][c]); scratch ab[d] */
-PQO_CLONES
-static void rotate_row(const float *x, const float *P, int64_t d, float *out, float *ab)
-{
-    for (int64_t kb = 0; kb < d; kb += PQO_KC) {
-        int64_t ke = kb + PQO_KC < d ? kb + PQO_KC : d;
-        for (int64_t c = 0; c < d; ++c) ab[c] = 0.0f;
-        for (int64_t k = kb; k < ke; ++k) {
-            const float xv = x[k];
-            const float *Pk = P + k * d;
-            for (int64_t c = 0; c < d; ++c) ab[c] = __builtin_fmaf(xv, Pk[c], ab[c]);
-        }
-        if (kb == 0)
-            for (int64_t c = 0; c < d; ++c) out[c] = ab[c];
-        else
-            for (int64_t c = 0; c < d; ++c) out[c] = out[c] + ab[c];
-    }
-}
+static void rotate_row(const float *x, const float *P, int64_t d, float *out, float *ab);
 
 /* x [n,d] strided (elements), out [n,d] contiguous */
 void pqo_rotate(const float *x, int64_t n, int64_t d, int64_t x_rs, int64_t x_cs, const float *P,
@@ -194,49 +171,43 @@ static void build_tables(enc_tables *t, const float *cb, int64_t M, int64_t K, i
 
 static void free_tables(enc_tables *t) { free(t->ct); free(t->cc); }
 
-/* one (already rotated, contiguous) row -> M codes (as int64 so any index width fits) */
-PQO_CLONES
+#define HOT_CAT2(a, b) a##b
+#define HOT_CAT(a, b) HOT_CAT2(a, b)
+#define HOT_NAME(f) HOT_CAT(f, _base)
+#define HOT_ATTR
+#include "pq_oracle_hot.h"
+#undef HOT_NAME
+#undef HOT_ATTR
+#if defined(__x86_64__)
+#define HOT_NAME(f) HOT_CAT(f, _avx2fma)
+#define HOT_ATTR __attribute__((target("avx2,fma")))
+#include "pq_oracle_hot.h"
+#undef HOT_NAME
+#undef HOT_ATTR
+static int have_avx2fma(void)
+{
+    return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+}
+#else
+static int have_avx2fma(void) { return 0; }
+#define rotate_row_avx2fma rotate_row_base
+#define encode_row_avx2fma encode_row_base
+#endif
+
+static void rotate_row(const float *x, const float *P, int64_t d, float *out, float *ab)
+{
+    if (have_avx2fma()) rotate_row_avx2fma(x, P, d, out, ab);
+    else rotate_row_base(x, P, d, out, ab);
+}
+
 static void encode_row(const enc_tables *t, const float *row, float *acc, int64_t *codes)
 {
-    const int64_t K = t->K, dsub = t->dsub;
-    for (int64_t m = 0; m < t->M; ++m) {
-        const float *xs = row + m * dsub;
-        const float xx = pqo_dot_unrolled(xs, xs, dsub);
-        const float *cc = t->cc + m * K;
-        /* (2) one fmaf chain per centroid, k ascending, restart every KC */
-        for (int64_t kb = 0; kb < dsub; kb += PQO_KC) {
-            int64_t ke = kb + PQO_KC < dsub ? kb + PQO_KC : dsub;
-            float *ab = (kb == 0) ? acc : acc + K;
-            for (int64_t j = 0; j < K; ++j) ab[j] = 0.0f;
-            for (int64_t k = kb; k < ke; ++k) {
-                const float xv = xs[k];
-                const float *ctk = t->ct + (m * dsub + k) * K;
-                for (int64_t j = 0; j < K; ++j) ab[j] = __builtin_fmaf(xv, ctk[j], ab[j]);
-            }
-            if (kb != 0)
-                for (int64_t j = 0; j < K; ++j) acc[j] = acc[j] + ab[j];
-        }
-        /* (3) combine */
-        int any_nan = 0;
-        for (int64_t j = 0; j < K; ++j) {
-            float tt = xx + cc[j];
-            float u = acc[j] + acc[j];
-            float dj = tt - u;
-            acc[j] = dj;
-            any_nan |= (dj != dj);
-        }
-        /* (4) first minimum */
-        int64_t best = 0;
-        if (any_nan) {
-            best = pqo_first_min(acc, K);
-        } else {
-            float bv = acc[0];
-            for (int64_t j = 1; j < K; ++j)
-                if (acc[j] < bv) { bv = acc[j]; best = j; }
-        }
-        codes[m] = best;
-    }
+    if (have_avx2fma()) encode_row_avx2fma(t, row, acc, codes);
+    else encode_row_base(t, row, acc, codes);
 }
+
+/* 1 when the AVX2+FMA build of the hot loops is in use (reported by the bench) */
+int pqo_uses_fma_simd(void) { return have_avx2fma(); }
 
 typedef struct {
     const enc_tables *t;
