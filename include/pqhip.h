@@ -1,0 +1,133 @@
+/*
+ * pqhip.h -- C ABI of libpqhip.so: MI355X (gfx950) product-quantizer encode / reconstruct.
+ *
+ * This is the drop-in boundary for ONE hot path of finalfusion/reductive v0.9.0: the bodies of
+ *   QuantizeVector::quantize_batch_into   src/pq/pq.rs:268-283  (-> src/pq/primitives.rs:64-104,
+ *                                          src/kmeans.rs:133-159, src/linalg.rs:150-180)
+ *   Reconstruct::reconstruct_batch_into   src/pq/pq.rs:309-327  (-> src/pq/primitives.rs:110-173)
+ * for A = f32.  The reference has no FFI of its own (it is a pure-Rust crate); the entry points
+ * below are exactly what a `extern "C"` block inside `impl QuantizeVector<f32> for Pq<f32>` binds
+ * (binding shown in INTEGRATION.md and rust/pqhip_ffi.rs).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - every function returns a pqhip_status (0 = OK); nothing throws, nothing aborts;
+ *  - strides are in ELEMENTS (ndarray convention), may be any non-negative value for host entry
+ *    points; device entry points need unit column stride;
+ *  - host pointers are only read/written during the call; handles own their device memory;
+ *  - all entry points are re-entrant and may be called concurrently from many threads
+ *    (`Pq<f32>` is `Send + Sync`; reference hot path is `&self`);
+ *  - results: u8/u16/u32 codes are bit-identical to the CANON-F32 arithmetic declared in
+ *    DESIGN.md (first index wins ties, NaN ordered last as ordered-float does); PQ
+ *    reconstructions are exact copies of codebook rows; OPQ reconstructions follow the same
+ *    chain rule and agree with the reference within 1e-5 relative.
+ *  - there is NO CPU fallback in this library: without a usable gfx950 device every compute
+ *    entry point returns PQHIP_ENODEV.
+ */
+#ifndef PQHIP_H
+#define PQHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQHIP_VERSION 100 /* 0.1.0 */
+
+typedef enum pqhip_status {
+    PQHIP_OK = 0,
+    PQHIP_EINVAL = 1,       /* null pointer / negative size / bad argument                     */
+    PQHIP_ESHAPE = 2,       /* "Quantizer and vector length mismatch" (primitives.rs:74-78),
+                               output-shape asserts (primitives.rs:80-87, 159-167),
+                               projection shape (pq.rs:46-55), empty quantizers (pq.rs:39-42)  */
+    PQHIP_ECODE_RANGE = 3,  /* a code >= K in reconstruct (reference: ndarray index_axis panic,
+                               primitives.rs:146)                                              */
+    PQHIP_EINDEX_WIDTH = 4, /* K-1 does not fit the index type (primitives.rs:31-34)           */
+    PQHIP_ENODEV = 5,       /* no gfx950 device / device index out of range                    */
+    PQHIP_EHIP = 6,         /* a HIP runtime call failed (pqhip_last_hip_error() has the text) */
+    PQHIP_ENOMEM = 7,       /* host or device allocation failed                                */
+    PQHIP_EUNSUPPORTED = 8  /* valid request this build has no kernel for                      */
+} pqhip_status;
+
+typedef struct pqhip_ctx pqhip_ctx;           /* a set of devices + per-device staging/streams */
+typedef struct pqhip_codebook pqhip_codebook; /* device-resident image of one `Pq<f32>`         */
+
+int32_t pqhip_version(void);
+const char *pqhip_strerror(int32_t status);
+/* text of the last failing HIP call on this thread ("" if none) */
+const char *pqhip_last_hip_error(void);
+
+/* number of visible HIP devices (0 and PQHIP_ENODEV if none) */
+int32_t pqhip_device_count(int32_t *out_count);
+
+/* devices == NULL / n_devices == 0  ->  all visible devices. */
+int32_t pqhip_ctx_create(const int32_t *devices, int32_t n_devices, pqhip_ctx **out);
+void pqhip_ctx_destroy(pqhip_ctx *ctx);
+int32_t pqhip_ctx_n_devices(const pqhip_ctx *ctx);
+
+/*
+ * Upload one product quantizer (replaces `Pq::new`, pq.rs:38-61, on the device side).
+ *   quantizers : [M][K][dsub] f32, C order          (Pq.quantizers, pq.rs:31)
+ *   projection : [d][d] f32 row-major, d = M*dsub, applied as x.dot(P) (pq.rs:276); NULL = plain PQ
+ * The codebook is replicated on every device of the ctx (<= 3 MB), no collective involved.
+ */
+int32_t pqhip_codebook_create(pqhip_ctx *ctx, const float *quantizers, int64_t n_subquantizers,
+                              int64_t n_centroids, int64_t sub_dim, const float *projection,
+                              pqhip_codebook **out);
+void pqhip_codebook_destroy(pqhip_codebook *cb);
+int64_t pqhip_codebook_quantized_len(const pqhip_codebook *cb);     /* M      pq.rs:300-302 */
+int64_t pqhip_codebook_reconstructed_len(const pqhip_codebook *cb); /* M*dsub pq.rs:345-347 */
+int64_t pqhip_codebook_n_centroids(const pqhip_codebook *cb);       /* K      pq.rs:103-105 */
+int32_t pqhip_codebook_has_projection(const pqhip_codebook *cb);
+
+/*
+ * HOST-buffer entry points: what `Pq::quantize_batch_into` / `reconstruct_batch_into` call.
+ * Rows are sharded contiguously over the ctx's devices, streamed through
+ * pinned staging buffers, results land in the caller's strided buffer.  code_bytes is
+ * sizeof(I) for the Rust index type I: 1 (u8), 2 (u16), 4 (u32) or 8 (usize/u64).
+ */
+int32_t pqhip_quantize_batch_f32(pqhip_codebook *cb, const float *x, int64_t n_rows,
+                                 int64_t x_row_stride, int64_t x_col_stride, void *codes,
+                                 int32_t code_bytes, int64_t codes_row_stride,
+                                 int64_t codes_col_stride);
+
+int32_t pqhip_reconstruct_batch_f32(pqhip_codebook *cb, const void *codes, int32_t code_bytes,
+                                    int64_t n_rows, int64_t codes_row_stride,
+                                    int64_t codes_col_stride, float *out, int64_t out_row_stride,
+                                    int64_t out_col_stride);
+
+/*
+ * DEVICE-resident entry points (inputs/outputs already in the HBM of device `device_slot` of the
+ * ctx; unit column stride; row strides in elements).  Asynchronous on `stream` (a hipStream_t
+ * passed as void*, NULL = the device's default stream); the caller synchronises.  Only u8 and
+ * u32 codes.  `scratch` for the OPQ variants is managed inside the codebook handle.
+ */
+int32_t pqhip_quantize_batch_f32_dev(pqhip_codebook *cb, int32_t device_slot, const float *d_x,
+                                     int64_t n_rows, int64_t x_row_stride, void *d_codes,
+                                     int32_t code_bytes, int64_t codes_row_stride, void *stream);
+
+int32_t pqhip_reconstruct_batch_f32_dev(pqhip_codebook *cb, int32_t device_slot,
+                                        const void *d_codes, int32_t code_bytes, int64_t n_rows,
+                                        int64_t codes_row_stride, float *d_out,
+                                        int64_t out_row_stride, void *stream);
+
+/* Reconstruct's range check is asynchronous on the device path: returns PQHIP_ECODE_RANGE if any
+ * device call since the last query saw a code >= K (synchronises `stream`). */
+int32_t pqhip_check_codes_dev(pqhip_codebook *cb, int32_t device_slot, void *stream);
+
+/* ---- knobs used by the test-suite and the bench (not part of the reference surface) -------- */
+/* force a kernel variant for encode: 0 = auto, 1 = scalar VALU anchor kernel, 2 = MFMA kernel  */
+int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);
+/* name of the encode kernel the last device call on this codebook launched ("" if none)        */
+const char *pqhip_last_encode_kernel(const pqhip_codebook *cb);
+
+/* Self-test of the hardware property the MFMA path rests on: v_mfma_f32_32x32x2_f32 must equal
+ * a k-ordered fmaf chain bit for bit.  Runs n_trials random 32x32xk tiles on device_slot;
+ * *out_mismatches receives the number of differing elements. */
+int32_t pqhip_selftest_mfma_chain(pqhip_ctx *ctx, int32_t device_slot, int32_t k, int32_t n_trials,
+                                  uint64_t seed, int64_t *out_mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQHIP_H */

@@ -1,0 +1,102 @@
+// common.hip.h -- device helpers shared by the gfx950 kernels of libpqhip.
+//
+// CANON-F32 distinguishes fused from unfused arithmetic, so this whole
+// library is compiled with -ffp-contract=off and the helpers below spell every rounding out.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma STDC FP_CONTRACT OFF
+
+namespace pqhip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kKC = 256;  // matrixmultiply sgemm k-block: chains restart every 256 k (rule 2)
+
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float ffma(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+
+// ordered-float 2 total order used by kmeans.rs:149-156: NaN greatest, NaN == NaN, -0 == +0.
+__device__ __forceinline__ bool of_less(float a, float b)
+{
+    if (a != a) return false;
+    if (b != b) return true;
+    return a < b;
+}
+
+// ndarray numeric_util::unrolled_dot(x, x) for a strided global vector (rule 1), runtime length.
+__device__ inline float norm_unrolled_global(const float* __restrict__ x, int n)
+{
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; n - i >= 8; i += 8) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) p[l] = fadd(p[l], fmul(x[i + l], x[i + l]));
+    }
+    float s = 0.f;
+    s = fadd(s, fadd(p[0], p[4]));
+    s = fadd(s, fadd(p[1], p[5]));
+    s = fadd(s, fadd(p[2], p[6]));
+    s = fadd(s, fadd(p[3], p[7]));
+    for (; i < n; ++i) s = fadd(s, fmul(x[i], x[i]));
+    return s;
+}
+
+// same, for a register-resident vector of compile-time length D.
+template <int D>
+__device__ __forceinline__ float norm_unrolled_static(const float (&v)[D])
+{
+    constexpr int NF = (D / 8) * 8;
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < NF; ++e) p[e & 7] = fadd(p[e & 7], fmul(v[e], v[e]));
+    float s = 0.f;
+    s = fadd(s, fadd(p[0], p[4]));
+    s = fadd(s, fadd(p[1], p[5]));
+    s = fadd(s, fadd(p[2], p[6]));
+    s = fadd(s, fadd(p[3], p[7]));
+#pragma unroll
+    for (int e = NF; e < D; ++e) s = fadd(s, fmul(v[e], v[e]));
+    return s;
+}
+
+// register-resident vector padded to DP, logical length n <= DP (wave-uniform).
+template <int DP>
+__device__ __forceinline__ float norm_unrolled_padded(const float (&v)[DP], int n)
+{
+    if (n == DP) return norm_unrolled_static<DP>(v);
+    const int nf = (n / 8) * 8;
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < DP; ++e)
+        if (e < nf) p[e & 7] = fadd(p[e & 7], fmul(v[e], v[e]));
+    float s = 0.f;
+    s = fadd(s, fadd(p[0], p[4]));
+    s = fadd(s, fadd(p[1], p[5]));
+    s = fadd(s, fadd(p[2], p[6]));
+    s = fadd(s, fadd(p[3], p[7]));
+#pragma unroll
+    for (int e = 0; e < DP; ++e)
+        if (e >= nf && e < n) s = fadd(s, fmul(v[e], v[e]));
+    return s;
+}
+
+// One sequential fmaf chain with restarts every kKC (rule 2), global operands with strides.
+__device__ inline float chain_dot_global(const float* __restrict__ a, int64_t as,
+                                         const float* __restrict__ b, int64_t bs, int n)
+{
+    float total = 0.f;
+    for (int kb = 0; kb < n; kb += kKC) {
+        const int ke = (kb + kKC < n) ? kb + kKC : n;
+        float ab = 0.f;
+        for (int k = kb; k < ke; ++k) ab = ffma(a[k * as], b[k * bs], ab);
+        total = (kb == 0) ? ab : fadd(total, ab);
+    }
+    return total;
+}
+
+}  // namespace pqhip

@@ -1,0 +1,296 @@
+// kernels_mfma.hip.h -- the gfx950 matrix-core kernels: PQ encode and the OPQ rotation GEMM.
+//
+// Why MFMA can be bit-exact here: on gfx950 v_mfma_f32_32x32x2_f32 computes, per output
+// element, D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) -- a k-ordered f32 fmaf chain with one
+// rounding per product and no wider internal accumulation.  Chaining the instruction over
+// k-steps s = 0,1,.. with k = 2s + (lane >> 5) therefore reproduces CANON-F32 rule 2
+// (matrixmultiply's sequential FMA micro-kernel) exactly.  pqhip_selftest_mfma_chain checks
+// that property on the device; the parity tests check the whole kernel against the oracle.
+//
+// Layouts of v_mfma_f32_32x32x2_f32 (wave64):
+//   A operand: lane l holds A[i = l & 31][k = l >> 5]          (one f32 VGPR)
+//   B operand: lane l holds B[k = l >> 5][j = l & 31]          (one f32 VGPR)
+//   C/D      : lane l, register r holds D[i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][j = l & 31]
+#pragma once
+#include "common.hip.h"
+
+namespace pqhip {
+
+// Above this squared norm (or for NaN/Inf) a tile leaves the fast epilogue: fma(-2, dp, t)
+// equals fl(t - fl(dp + dp)) only while dp + dp cannot overflow; |dp| <= sqrt(xx * cc) keeps
+// that true with a wide margin below 2^100.
+constexpr float kBigNorm = 1.2676506e30f;  // 2^100
+
+struct EncodeArgs {
+    const float* x;      // [n][x_rs] rows, unit column stride
+    int64_t n;
+    int64_t x_rs;
+    void* out;           // [n][o_rs] codes
+    int64_t o_rs;
+    const float* frags;  // [M][T][S][64]  (k_build_frags)
+    const float* cc;     // [M][T*32]      (k_centroid_norms, +inf padded)
+    const float* cb;     // [M][K][dsub]   row-major codebook (slow path only)
+    int M, K, dsub;
+    int k_pad;           // T * 32 (row length of cc)
+    int rows_per_item;   // multiple of 32
+    int64_t n_chunks;    // ceil(n / rows_per_item)
+    int64_t chunks_per_xcd;  // ceil(n_chunks / 8)
+};
+
+// Exact-by-construction tile evaluation used when a tile holds NaN/Inf/huge values: lanes of
+// the lower half scan all K centroids with the literal three-operation distance and the
+// ordered-float comparison.  Rare; kept out of line so it costs the fast path no registers.
+template <typename IdxT>
+__device__ __noinline__ void encode_tile_slow(const EncodeArgs& a, int m, int64_t row, bool valid)
+{
+    if (!valid || (threadIdx.x & 32)) return;
+    const float* xs = a.x + row * a.x_rs + (int64_t)m * a.dsub;
+    const float* cbm = a.cb + (int64_t)m * a.K * a.dsub;
+    const float* ccm = a.cc + (int64_t)m * a.k_pad;
+    const float xx = norm_unrolled_global(xs, a.dsub);
+    int best = 0;
+    float bestd = 0.f;
+    for (int j = 0; j < a.K; ++j) {
+        const float dp = chain_dot_global(xs, 1, cbm + (int64_t)j * a.dsub, 1, a.dsub);
+        const float d = fsub(fadd(xx, ccm[j]), fadd(dp, dp));
+        if (j == 0 || of_less(d, bestd)) { bestd = d; best = j; }
+    }
+    reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1  pq_encode  (primitives.rs:89-103 -> kmeans.rs:141-156 -> linalg.rs:167-176, fused)
+//
+// Codebook-stationary: one WAVE owns one (row-chunk, subquantizer m) item and keeps the whole
+// sub-codebook of m -- T tiles of 32 centroids x S k-steps -- in T*S VGPRs as MFMA A operands
+// for the lifetime of the item.  It then streams 32-row tiles of x: the 32 sub-vectors are the
+// B operand (x row on the lane), so each lane ends up with the 16 x T distances of ITS row in
+// its own accumulator registers and the argmin over centroids is lane-local; only the two
+// half-waves (centroid rows +0..3 vs +4..7 of every group of 8) are merged by one shuffle.
+// No LDS traffic for operands, no barriers in the loop; ||c||^2 is the only LDS resident.
+//
+// Item -> wave mapping is XCD-aware: workgroup b runs on XCD (b % 8) (observed round-robin;
+// speed only), and all M items of one row chunk are given to consecutive waves of ONE XCD, so
+// the M sub-vector slices of an x row are pulled from HBM once and then hit that XCD's L2.
+//
+// T  : centroid tiles (K padded to 32 T with +inf-norm dummies)
+// DP : dsub padded to a multiple of 4 (zero k-padding is exact: fma(0, 0, acc) == acc)
+// VEC: x rows are 16-byte aligned and dsub % 4 == 0 -> global_load_dwordx4
+// ---------------------------------------------------------------------------------------------
+template <int T, int DP, bool VEC, typename IdxT>
+__global__ __launch_bounds__(256, 2) void k_encode_mfma(EncodeArgs a)
+{
+    constexpr int S = DP / 2;
+    __shared__ float cc_s[4][T * 32];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+
+    // ---- item mapping (wave-uniform) ----
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t sidx = (b >> 3) * 4 + wave;  // position in this XCD's item stream
+    const int64_t chunk_local = sidx / a.M;
+    const int m = (int)(sidx - chunk_local * a.M);
+    const int64_t chunk = chunk_local * 8 + xcd;
+    const bool active = (chunk_local < a.chunks_per_xcd) && (chunk < a.n_chunks);
+
+    // ---- resident operands ----
+    float af[T][S];
+    if (active) {
+        const float* fp = a.frags + (int64_t)m * T * S * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int s = 0; s < S; ++s) af[t][s] = fp[(t * S + s) * 64];
+        const float* ccm = a.cc + (int64_t)m * T * 32;
+        for (int i = lane; i < T * 32; i += 64) cc_s[wave][i] = ccm[i];
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int s = 0; s < S; ++s) af[t][s] = 0.f;
+    }
+    __syncthreads();  // every wave reaches this exactly once
+    if (!active) return;
+
+    const int64_t row_begin = chunk * a.rows_per_item;
+    int64_t row_end = row_begin + a.rows_per_item;
+    if (row_end > a.n) row_end = a.n;
+    const float* xcol = a.x + (int64_t)m * a.dsub;
+    const int dsub = a.dsub;
+
+    auto load_tile = [&](float (&v)[DP], int64_t tile_row0) {
+        int64_t row = tile_row0 + j;
+        if (row >= a.n) row = a.n - 1;  // clamp: loads stay in bounds, result is not stored
+        const float* p = xcol + row * a.x_rs;
+        if (VEC) {
+#pragma unroll
+            for (int e = 0; e < DP; e += 4) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(p + e);
+                v[e] = q[0]; v[e + 1] = q[1]; v[e + 2] = q[2]; v[e + 3] = q[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < DP; ++e) v[e] = (e < dsub) ? p[e] : 0.f;
+        }
+    };
+
+    float v[DP];
+    load_tile(v, row_begin);
+
+    for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
+        float vn[DP];
+        const int64_t next0 = (row0 + 32 < row_end) ? row0 + 32 : row0;
+        load_tile(vn, next0);  // prefetch (re-reads the last tile once at the end; harmless)
+
+        const float xx = norm_unrolled_padded<DP>(v, dsub);
+        float bop[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) bop[s] = h ? v[2 * s + 1] : v[2 * s];
+
+        const int64_t row = row0 + j;
+        const bool valid = row < a.n;
+        const bool fast_ok = xx < kBigNorm;  // false for NaN / Inf / huge
+        if (__builtin_amdgcn_ballot_w64(!fast_ok) != 0ull) {
+            encode_tile_slow<IdxT>(a, m, row, valid);
+        } else {
+            float best = __builtin_inff();
+            int bidx = 0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                              0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][s], bop[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // ||c||^2 of centroids 32t + 8g + 4h + {0,1,2,3}: one ds_read_b128
+                    const f32x4 c4 =
+                        *reinterpret_cast<const f32x4*>(&cc_s[wave][32 * t + 8 * g + 4 * h]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float tt = fadd(xx, c4[q]);
+                        // == fl(tt - fl(dp + dp)): 2*dp is exact and cannot overflow here
+                        const float d = ffma(acc[4 * g + q], -2.0f, tt);
+                        const bool lt = d < best;
+                        best = lt ? d : best;
+                        bidx = lt ? (32 * t + 8 * g + q) : bidx;
+                    }
+                }
+            }
+            bidx += 4 * h;
+            // merge the two half-waves: lexicographic (distance, index) minimum
+            const float od = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(bidx, 32);
+            if (od < best || (od == best && oi < bidx)) bidx = oi;
+            if (h == 0 && valid) reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
+        }
+#pragma unroll
+        for (int e = 0; e < DP; ++e) v[e] = vn[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2/K4  rotation GEMM   out[n][c] = sum_k x[n][k] * Pm[k][c]     (pq.rs:276, pq.rs:324)
+// with the matrixmultiply k-blocking of rule 2: chain(0..255) + chain(256..511) + ...
+// Wave tile 32 rows x 64 columns (two 32x32 accumulators + two more for the current k-block),
+// workgroup = 4 waves stacked on rows.  x is the A operand (row on the lane, k on the
+// half-wave), Pm the B operand (coalesced 128-B rows).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_rotate_mfma(const float* __restrict__ x, int64_t n,
+                                                        int64_t x_rs,
+                                                        const float* __restrict__ Pm, int d,
+                                                        float* __restrict__ out, int64_t o_rs)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    if (row0 >= n) return;
+    const int c0 = blockIdx.y * 64;
+
+    int64_t arow = row0 + j;
+    if (arow >= n) arow = n - 1;
+    const float* xr = x + arow * x_rs;
+    const int cA = c0 + j, cB = c0 + 32 + j;
+    const bool okA = cA < d, okB = cB < d;
+
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                         0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 totA = zero, totB = zero;
+    for (int kb = 0; kb < d; kb += kKC) {
+        const int ke = (kb + kKC < d) ? kb + kKC : d;
+        f32x16 accA = zero, accB = zero;
+        for (int k0 = kb; k0 < ke; k0 += 2) {
+            const int k = k0 + h;
+            const bool kok = k < ke;
+            const float av = kok ? xr[k] : 0.f;
+            const float* prow = Pm + (int64_t)(kok ? k : 0) * d;
+            const float bA = (kok && okA) ? prow[cA] : 0.f;
+            const float bB = (kok && okB) ? prow[cB] : 0.f;
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bA, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bB, accB, 0, 0, 0);
+        }
+        if (kb == 0) {
+            totA = accA; totB = accB;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { totA[r] = fadd(totA[r], accA[r]); totB[r] = fadd(totB[r], accB[r]); }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < n) {
+            if (okA) out[row * o_rs + cA] = totA[r];
+            if (okB) out[row * o_rs + cB] = totB[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device self-test of the MFMA == fmaf-chain property (pqhip_selftest_mfma_chain).
+// One wave per trial: random A[32][k], B[k][32]; compares the MFMA tile with a scalar chain.
+// ---------------------------------------------------------------------------------------------
+__device__ inline float hash_unit(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    // value in (-4, 4) with a random exponent spread so that rounding really happens
+    const float u = (float)(int)((x >> 40) & 0xFFFFFF) / 16777216.0f - 0.5f;
+    const int e = (int)((x >> 8) & 7) - 3;
+    return ldexpf(u, e);
+}
+
+__global__ void k_selftest_mfma_chain(int k, uint64_t seed, unsigned long long* mismatches)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t base = seed + (uint64_t)blockIdx.x * 1000003ull;
+    auto A = [&](int i, int kk) { return hash_unit(base * 31 + (uint64_t)i * 4099 + kk); };
+    auto B = [&](int kk, int jj) { return hash_unit(base * 17 + (uint64_t)jj * 8209 + kk + 77777); };
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < k; k0 += 2) {
+        const int kk = k0 + h;
+        const float av = (kk < k) ? A(j, kk) : 0.f;
+        const float bv = (kk < k) ? B(kk, j) : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    unsigned long long bad = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float ref = 0.f;
+        for (int kk = 0; kk < k; ++kk) ref = ffma(A(i, kk), B(kk, j), ref);
+        if (__float_as_uint(ref) != __float_as_uint(acc[r])) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+}  // namespace pqhip

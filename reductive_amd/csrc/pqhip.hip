@@ -1,0 +1,735 @@
+// pqhip.hip -- C ABI (include/pqhip.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary: context/device management, codebook upload and
+// preparation, row sharding over devices (contiguous row ranges, codebook
+// replicated, no collective), pinned double-buffered staging for host-resident calls, and the
+// launch logic that picks a kernel variant.  There is deliberately NO CPU compute fallback
+// here: if HIP or a device is missing every compute entry point returns an error status.
+#include "../../include/pqhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels_basic.hip.h"
+#include "kernels_mfma.hip.h"
+
+using namespace pqhip;
+
+namespace {
+
+thread_local std::string g_hip_err;
+
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            g_hip_err = std::string(#call) + ": " + hipGetErrorString(e__);                  \
+            (void)hipGetLastError();                                                         \
+            return (e__ == hipErrorOutOfMemory) ? PQHIP_ENOMEM : PQHIP_EHIP;                  \
+        }                                                                                    \
+    } while (0)
+
+#define PQCHK(call)                      \
+    do {                                 \
+        int32_t s__ = (call);            \
+        if (s__ != PQHIP_OK) return s__; \
+    } while (0)
+
+constexpr int64_t kStageRows = 1 << 16;      // rows per staging buffer (host-resident calls)
+constexpr int64_t kScratchRowsMax = 1 << 20;  // rows per OPQ scratch chunk (device calls)
+
+struct Staging {
+    void* h_in = nullptr;   // pinned
+    void* h_out = nullptr;  // pinned
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    size_t in_bytes = 0, out_bytes = 0;
+};
+
+struct DeviceSlot {
+    int ordinal = -1;
+    std::mutex mu;  // serialises host-resident calls and scratch (re)allocation on this device
+    hipStream_t stream[2] = {nullptr, nullptr};
+    Staging st[2];
+};
+
+struct CodebookDev {
+    float* cb = nullptr;     // [M][K][dsub]
+    float* frags = nullptr;  // [M][T][S][64]
+    float* cc = nullptr;     // [M][k_pad]
+    float* P = nullptr;      // [d][d]   x.dot(P)
+    float* PT = nullptr;     // [d][d]   r.dot(P^T)
+    int* err = nullptr;      // bit 0: code >= K seen by reconstruct
+    float* scratch = nullptr;
+    int64_t scratch_rows = 0;
+    hipEvent_t scratch_done = nullptr;
+};
+
+}  // namespace
+
+struct pqhip_ctx {
+    std::vector<std::unique_ptr<DeviceSlot>> devs;
+};
+
+struct pqhip_codebook {
+    pqhip_ctx* ctx = nullptr;
+    int64_t M = 0, K = 0, dsub = 0, d = 0;
+    bool has_proj = false;
+    // MFMA encode geometry (0 = shape not covered, anchor kernel is used)
+    int T = 0, DP = 0, k_pad = 0;
+    bool norms_ok = false;  // all ||c||^2 finite and < 2^100
+    int variant = 0;        // 0 auto, 1 anchor, 2 mfma
+    std::vector<CodebookDev> dev;
+    std::atomic<const char*> last_kernel{""};
+    std::mutex mu;  // guards scratch (re)allocation
+};
+
+namespace {
+
+int32_t ensure_staging(Staging& s, size_t in_bytes, size_t out_bytes)
+{
+    if (s.in_bytes < in_bytes) {
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.d_in) (void)hipFree(s.d_in);
+        s.h_in = s.d_in = nullptr;
+        s.in_bytes = 0;
+        HIPCHK(hipHostMalloc(&s.h_in, in_bytes, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&s.d_in, in_bytes));
+        s.in_bytes = in_bytes;
+    }
+    if (s.out_bytes < out_bytes) {
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        if (s.d_out) (void)hipFree(s.d_out);
+        s.h_out = s.d_out = nullptr;
+        s.out_bytes = 0;
+        HIPCHK(hipHostMalloc(&s.h_out, out_bytes, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&s.d_out, out_bytes));
+        s.out_bytes = out_bytes;
+    }
+    return PQHIP_OK;
+}
+
+void free_staging(Staging& s)
+{
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_out) (void)hipFree(s.d_out);
+    s = Staging();
+}
+
+// ---- MFMA encode dispatch ------------------------------------------------------------------
+template <int T, int DP, typename IdxT>
+void launch_encode_mfma_vec(bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
+{
+    if (vec)
+        hipLaunchKernelGGL((k_encode_mfma<T, DP, true, IdxT>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_encode_mfma<T, DP, false, IdxT>), grid, dim3(256), 0, st, a);
+}
+
+template <int T, typename IdxT>
+bool launch_encode_mfma_dp(int DP, bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
+{
+    switch (DP) {
+    case 4: launch_encode_mfma_vec<T, 4, IdxT>(vec, a, grid, st); return true;
+    case 8: launch_encode_mfma_vec<T, 8, IdxT>(vec, a, grid, st); return true;
+    case 12: launch_encode_mfma_vec<T, 12, IdxT>(vec, a, grid, st); return true;
+    case 16: launch_encode_mfma_vec<T, 16, IdxT>(vec, a, grid, st); return true;
+    case 20: launch_encode_mfma_vec<T, 20, IdxT>(vec, a, grid, st); return true;
+    case 24: launch_encode_mfma_vec<T, 24, IdxT>(vec, a, grid, st); return true;
+    case 28: launch_encode_mfma_vec<T, 28, IdxT>(vec, a, grid, st); return true;
+    case 32: launch_encode_mfma_vec<T, 32, IdxT>(vec, a, grid, st); return true;
+    default: return false;
+    }
+}
+
+template <typename IdxT>
+bool launch_encode_mfma(int T, int DP, bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
+{
+    switch (T) {
+    case 1: return launch_encode_mfma_dp<1, IdxT>(DP, vec, a, grid, st);
+    case 2: return launch_encode_mfma_dp<2, IdxT>(DP, vec, a, grid, st);
+    case 4: return launch_encode_mfma_dp<4, IdxT>(DP, vec, a, grid, st);
+    case 8: return launch_encode_mfma_dp<8, IdxT>(DP, vec, a, grid, st);
+    default: return false;
+    }
+}
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// PQ encode of device-resident, already rotated rows.
+int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
+                         void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st)
+{
+    if (n == 0) return PQHIP_OK;
+    CodebookDev& cd = cb->dev[slot];
+    // the MFMA kernel emits u8 codes (K <= 256); 32-bit codes take the anchor kernel for now
+    const bool mfma_possible = cb->T != 0 && cb->norms_ok && code_bytes == 1;
+    bool use_mfma = mfma_possible;
+    if (cb->variant == 1) use_mfma = false;
+    if (cb->variant == 2 && !mfma_possible) return PQHIP_EUNSUPPORTED;
+
+    if (use_mfma) {
+        EncodeArgs a;
+        a.x = d_x; a.n = n; a.x_rs = x_rs; a.out = d_codes; a.o_rs = o_rs;
+        a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
+        a.M = (int)cb->M; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
+        // ~2 items per wave slot (256 CUs x 8 waves), 32..1024 rows each
+        int64_t rpi = round_up((n * cb->M + 4095) / 4096, 32);
+        rpi = std::max<int64_t>(32, std::min<int64_t>(1024, rpi));
+        a.rows_per_item = (int)rpi;
+        a.n_chunks = (n + rpi - 1) / rpi;
+        a.chunks_per_xcd = (a.n_chunks + 7) / 8;
+        const int64_t items_per_xcd = a.chunks_per_xcd * cb->M;
+        const int64_t wgs_per_xcd = (items_per_xcd + 3) / 4;
+        const dim3 grid((unsigned)(wgs_per_xcd * 8));
+        const bool vec = (cb->dsub % 4 == 0) && (cb->DP == cb->dsub) && (x_rs % 4 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
+        if (!launch_encode_mfma<uint8_t>(cb->T, cb->DP, vec, a, grid, st)) return PQHIP_EUNSUPPORTED;
+        cb->last_kernel = vec ? "k_encode_mfma<vec4>" : "k_encode_mfma<scalar-load>";
+    } else {
+        const int64_t total = n * cb->M;
+        const int block = 256;
+        const unsigned grid = (unsigned)std::min<int64_t>((total + block - 1) / block, 256 * 32);
+        if (code_bytes == 1)
+            hipLaunchKernelGGL((k_encode_scalar<uint8_t>), dim3(grid), dim3(block), 0, st, d_x, n,
+                               x_rs, (uint8_t*)d_codes, o_rs, cd.cb, cd.cc, (int)cb->M, (int)cb->K,
+                               (int)cb->dsub, cb->k_pad);
+        else if (code_bytes == 4)
+            hipLaunchKernelGGL((k_encode_scalar<uint32_t>), dim3(grid), dim3(block), 0, st, d_x, n,
+                               x_rs, (uint32_t*)d_codes, o_rs, cd.cb, cd.cc, (int)cb->M, (int)cb->K,
+                               (int)cb->dsub, cb->k_pad);
+        else
+            return PQHIP_EUNSUPPORTED;
+        cb->last_kernel = "k_encode_scalar";
+    }
+    HIPCHK(hipGetLastError());
+    return PQHIP_OK;
+}
+
+// out[n][d] = x[n][d] . Pm   on the device
+int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, int d, float* d_out,
+                   int64_t o_rs, hipStream_t st)
+{
+    if (n == 0) return PQHIP_OK;
+    const dim3 grid((unsigned)((n + 127) / 128), (unsigned)((d + 63) / 64));
+    hipLaunchKernelGGL(k_rotate_mfma, grid, dim3(256), 0, st, d_x, n, x_rs, Pm, d, d_out, o_rs);
+    HIPCHK(hipGetLastError());
+    return PQHIP_OK;
+}
+
+int32_t ensure_scratch(pqhip_codebook* cb, int slot, int64_t rows)
+{
+    CodebookDev& cd = cb->dev[slot];
+    if (cd.scratch_rows >= rows) return PQHIP_OK;
+    std::lock_guard<std::mutex> g(cb->mu);
+    if (cd.scratch_rows >= rows) return PQHIP_OK;
+    if (cd.scratch) {
+        HIPCHK(hipDeviceSynchronize());
+        (void)hipFree(cd.scratch);
+        cd.scratch = nullptr;
+        cd.scratch_rows = 0;
+    }
+    HIPCHK(hipMalloc((void**)&cd.scratch, (size_t)rows * cb->d * sizeof(float)));
+    cd.scratch_rows = rows;
+    return PQHIP_OK;
+}
+
+int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes, int64_t n,
+                   int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st)
+{
+    if (n == 0) return PQHIP_OK;
+    CodebookDev& cd = cb->dev[slot];
+    const int d = (int)cb->d;
+    const bool vec = (cb->dsub % 4 == 0) && (o_rs % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
+    const int cpr = vec ? d / 4 : d;
+    const int rows_per_block = 64;
+    const unsigned grid =
+        (unsigned)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, 256 * 8);
+    const size_t lds = (size_t)cpr * sizeof(int);
+#define LAUNCH_REC(IDX, V)                                                                        \
+    hipLaunchKernelGGL((k_reconstruct<IDX, V>), dim3(grid), dim3(256), lds, st,                   \
+                       (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K,  \
+                       (int)cb->dsub, rows_per_block, cd.err)
+    if (code_bytes == 1) { if (vec) LAUNCH_REC(uint8_t, 4); else LAUNCH_REC(uint8_t, 1); }
+    else if (code_bytes == 4) { if (vec) LAUNCH_REC(uint32_t, 4); else LAUNCH_REC(uint32_t, 1); }
+    else return PQHIP_EUNSUPPORTED;
+#undef LAUNCH_REC
+    HIPCHK(hipGetLastError());
+    return PQHIP_OK;
+}
+
+int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
+                          void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st)
+{
+    if (!cb->has_proj) return encode_plain_dev(cb, slot, d_x, n, x_rs, d_codes, code_bytes, o_rs, st);
+    // OPQ (pq.rs:276): rx = x.dot(P) into scratch, chunked, then PQ encode of rx
+    const int64_t chunk = std::min<int64_t>(n, kScratchRowsMax);
+    PQCHK(ensure_scratch(cb, slot, chunk));
+    CodebookDev& cd = cb->dev[slot];
+    HIPCHK(hipStreamWaitEvent(st, cd.scratch_done, 0));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t rows = std::min<int64_t>(chunk, n - r0);
+        PQCHK(rotate_dev(d_x + r0 * x_rs, rows, x_rs, cd.P, (int)cb->d, cd.scratch, cb->d, st));
+        PQCHK(encode_plain_dev(cb, slot, cd.scratch, rows, cb->d,
+                               (char*)d_codes + r0 * o_rs * code_bytes, code_bytes, o_rs, st));
+    }
+    HIPCHK(hipEventRecord(cd.scratch_done, st));
+    return PQHIP_OK;
+}
+
+int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes,
+                             int64_t n, int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st)
+{
+    if (!cb->has_proj) return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st);
+    // OPQ (pq.rs:323-326): gather into scratch, then out = r.dot(P^T)
+    const int64_t chunk = std::min<int64_t>(n, kScratchRowsMax);
+    PQCHK(ensure_scratch(cb, slot, chunk));
+    CodebookDev& cd = cb->dev[slot];
+    HIPCHK(hipStreamWaitEvent(st, cd.scratch_done, 0));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t rows = std::min<int64_t>(chunk, n - r0);
+        PQCHK(gather_dev(cb, slot, (const char*)d_codes + r0 * c_rs * code_bytes, code_bytes, rows,
+                         c_rs, cd.scratch, cb->d, st));
+        PQCHK(rotate_dev(cd.scratch, rows, cb->d, cd.PT, (int)cb->d, d_out + r0 * o_rs, o_rs, st));
+    }
+    HIPCHK(hipEventRecord(cd.scratch_done, st));
+    return PQHIP_OK;
+}
+
+// run fn(slot, row_begin, row_end) for the contiguous row shard of every device
+template <typename F>
+int32_t for_each_shard(pqhip_ctx* ctx, int64_t n, F fn)
+{
+    const int nd = (int)ctx->devs.size();
+    const int used = (int)std::max<int64_t>(1, std::min<int64_t>(nd, (n + 4095) / 4096));
+    const int64_t per = (n + used - 1) / used;
+    if (used == 1) return fn(0, (int64_t)0, n);
+    std::vector<int32_t> rc(used, PQHIP_OK);
+    std::vector<std::thread> th;
+    for (int i = 0; i < used; ++i) {
+        const int64_t b = std::min<int64_t>(n, i * per), e = std::min<int64_t>(n, b + per);
+        th.emplace_back([&, i, b, e] { rc[i] = fn(i, b, e); });
+    }
+    for (auto& t : th) t.join();
+    for (int32_t r : rc)
+        if (r != PQHIP_OK) return r;
+    return PQHIP_OK;
+}
+
+void store_code(void* base, int bytes, int64_t off, uint32_t v)
+{
+    switch (bytes) {
+    case 1: ((uint8_t*)base)[off] = (uint8_t)v; break;
+    case 2: ((uint16_t*)base)[off] = (uint16_t)v; break;
+    case 4: ((uint32_t*)base)[off] = v; break;
+    default: ((uint64_t*)base)[off] = v; break;
+    }
+}
+
+uint64_t load_code(const void* base, int bytes, int64_t off)
+{
+    switch (bytes) {
+    case 1: return ((const uint8_t*)base)[off];
+    case 2: return ((const uint16_t*)base)[off];
+    case 4: return ((const uint32_t*)base)[off];
+    default: return ((const uint64_t*)base)[off];
+    }
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int32_t pqhip_version(void) { return PQHIP_VERSION; }
+
+const char* pqhip_strerror(int32_t s)
+{
+    switch (s) {
+    case PQHIP_OK: return "ok";
+    case PQHIP_EINVAL: return "invalid argument";
+    case PQHIP_ESHAPE: return "shape mismatch (quantizer / vector / output lengths)";
+    case PQHIP_ECODE_RANGE: return "code out of range (>= number of centroids)";
+    case PQHIP_EINDEX_WIDTH: return "cannot store centroids in quantizer index type";
+    case PQHIP_ENODEV: return "no usable HIP device";
+    case PQHIP_EHIP: return "HIP runtime error";
+    case PQHIP_ENOMEM: return "out of memory";
+    case PQHIP_EUNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+    }
+}
+
+const char* pqhip_last_hip_error(void) { return g_hip_err.c_str(); }
+
+int32_t pqhip_device_count(int32_t* out)
+{
+    if (!out) return PQHIP_EINVAL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        *out = 0;
+        return PQHIP_ENODEV;
+    }
+    *out = n;
+    return PQHIP_OK;
+}
+
+int32_t pqhip_ctx_create(const int32_t* devices, int32_t n_devices, pqhip_ctx** out)
+{
+    if (!out || n_devices < 0) return PQHIP_EINVAL;
+    *out = nullptr;
+    int32_t avail = 0;
+    PQCHK(pqhip_device_count(&avail));
+    std::vector<int> ords;
+    if (!devices || n_devices == 0) {
+        for (int i = 0; i < avail; ++i) ords.push_back(i);
+    } else {
+        for (int i = 0; i < n_devices; ++i) {
+            if (devices[i] < 0 || devices[i] >= avail) return PQHIP_ENODEV;
+            ords.push_back(devices[i]);
+        }
+    }
+    std::unique_ptr<pqhip_ctx> ctx(new pqhip_ctx());
+    for (int o : ords) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, o));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            g_hip_err = std::string("device is ") + prop.gcnArchName + ", library is built for gfx950";
+            return PQHIP_ENODEV;
+        }
+        std::unique_ptr<DeviceSlot> ds(new DeviceSlot());
+        ds->ordinal = o;
+        HIPCHK(hipSetDevice(o));
+        HIPCHK(hipStreamCreateWithFlags(&ds->stream[0], hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&ds->stream[1], hipStreamNonBlocking));
+        ctx->devs.push_back(std::move(ds));
+    }
+    *out = ctx.release();
+    return PQHIP_OK;
+}
+
+void pqhip_ctx_destroy(pqhip_ctx* ctx)
+{
+    if (!ctx) return;
+    for (auto& ds : ctx->devs) {
+        (void)hipSetDevice(ds->ordinal);
+        for (int i = 0; i < 2; ++i) {
+            if (ds->stream[i]) { (void)hipStreamSynchronize(ds->stream[i]); (void)hipStreamDestroy(ds->stream[i]); }
+            free_staging(ds->st[i]);
+        }
+    }
+    delete ctx;
+}
+
+int32_t pqhip_ctx_n_devices(const pqhip_ctx* ctx) { return ctx ? (int32_t)ctx->devs.size() : 0; }
+
+int32_t pqhip_codebook_create(pqhip_ctx* ctx, const float* quantizers, int64_t M, int64_t K,
+                              int64_t dsub, const float* projection, pqhip_codebook** out)
+{
+    if (!ctx || !out) return PQHIP_EINVAL;
+    *out = nullptr;
+    if (!quantizers) return PQHIP_EINVAL;
+    if (M <= 0 || K <= 0 || dsub <= 0) return PQHIP_ESHAPE;  // pq.rs:39-42 "without quantizers"
+    if (M > 65535 || dsub > 65535 || K > (1ll << 31) - 1 || M * dsub > (1 << 24)) return PQHIP_EUNSUPPORTED;
+
+    std::unique_ptr<pqhip_codebook> cb(new pqhip_codebook());
+    cb->ctx = ctx;
+    cb->M = M; cb->K = K; cb->dsub = dsub; cb->d = M * dsub;
+    cb->has_proj = projection != nullptr;
+    // MFMA geometry: K <= 256 padded to {1,2,4,8} tiles of 32; dsub <= 32 padded to a multiple
+    // of 4; resident A fragments must fit the register file (T * DP/2 <= 128).
+    int T = 0, DP = 0;
+    if (K <= 256 && dsub <= 32) {
+        const int tiles = (int)((K + 31) / 32);
+        T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
+        DP = (int)round_up(dsub, 4);
+        if (T * (DP / 2) > 128) { T = 0; DP = 0; }
+    }
+    cb->T = T; cb->DP = DP;
+    cb->k_pad = T ? T * 32 : (int)round_up(K, 32);
+    const int S = DP / 2;
+
+    std::vector<float> PT;
+    if (projection) {
+        PT.resize((size_t)cb->d * cb->d);
+        for (int64_t k = 0; k < cb->d; ++k)
+            for (int64_t c = 0; c < cb->d; ++c) PT[c * cb->d + k] = projection[k * cb->d + c];
+    }
+
+    cb->dev.resize(ctx->devs.size());
+    bool norms_ok = true;
+    for (size_t i = 0; i < ctx->devs.size(); ++i) {
+        CodebookDev& cd = cb->dev[i];
+        HIPCHK(hipSetDevice(ctx->devs[i]->ordinal));
+        hipStream_t st = ctx->devs[i]->stream[0];
+        const size_t cb_bytes = (size_t)(M * K * dsub) * sizeof(float);
+        HIPCHK(hipMalloc((void**)&cd.cb, cb_bytes));
+        HIPCHK(hipMemcpyAsync(cd.cb, quantizers, cb_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMalloc((void**)&cd.cc, (size_t)M * cb->k_pad * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&cd.err, 2 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(cd.err, 0, 2 * sizeof(int), st));
+        HIPCHK(hipEventCreateWithFlags(&cd.scratch_done, hipEventDisableTiming));
+        {
+            const int total = (int)(M * cb->k_pad);
+            hipLaunchKernelGGL(k_centroid_norms, dim3((total + 255) / 256), dim3(256), 0, st, cd.cb,
+                               (int)M, (int)K, (int)dsub, cb->k_pad, cd.cc);
+            hipLaunchKernelGGL(k_check_norms, dim3((total + 255) / 256), dim3(256), 0, st, cd.cc,
+                               (int)M, (int)K, cb->k_pad, kBigNorm, cd.err + 1);
+        }
+        if (T) {
+            const int64_t total = M * T * S * 64;
+            HIPCHK(hipMalloc((void**)&cd.frags, (size_t)total * sizeof(float)));
+            hipLaunchKernelGGL(k_build_frags, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                               cd.cb, (int)M, (int)K, (int)dsub, T, S, cd.frags);
+        }
+        if (projection) {
+            const size_t pb = (size_t)cb->d * cb->d * sizeof(float);
+            HIPCHK(hipMalloc((void**)&cd.P, pb));
+            HIPCHK(hipMalloc((void**)&cd.PT, pb));
+            HIPCHK(hipMemcpyAsync(cd.P, projection, pb, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(cd.PT, PT.data(), pb, hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(hipGetLastError());
+        int bad = 0;
+        HIPCHK(hipMemcpyAsync(&bad, cd.err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (bad) norms_ok = false;
+        HIPCHK(hipEventRecord(cd.scratch_done, st));
+    }
+    cb->norms_ok = norms_ok;
+    *out = cb.release();
+    return PQHIP_OK;
+}
+
+void pqhip_codebook_destroy(pqhip_codebook* cb)
+{
+    if (!cb) return;
+    for (size_t i = 0; i < cb->dev.size(); ++i) {
+        CodebookDev& cd = cb->dev[i];
+        (void)hipSetDevice(cb->ctx->devs[i]->ordinal);
+        (void)hipDeviceSynchronize();
+        if (cd.cb) (void)hipFree(cd.cb);
+        if (cd.frags) (void)hipFree(cd.frags);
+        if (cd.cc) (void)hipFree(cd.cc);
+        if (cd.P) (void)hipFree(cd.P);
+        if (cd.PT) (void)hipFree(cd.PT);
+        if (cd.err) (void)hipFree(cd.err);
+        if (cd.scratch) (void)hipFree(cd.scratch);
+        if (cd.scratch_done) (void)hipEventDestroy(cd.scratch_done);
+    }
+    delete cb;
+}
+
+int64_t pqhip_codebook_quantized_len(const pqhip_codebook* cb) { return cb ? cb->M : 0; }
+int64_t pqhip_codebook_reconstructed_len(const pqhip_codebook* cb) { return cb ? cb->d : 0; }
+int64_t pqhip_codebook_n_centroids(const pqhip_codebook* cb) { return cb ? cb->K : 0; }
+int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && cb->has_proj; }
+
+int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
+{
+    if (!cb || variant < 0 || variant > 2) return PQHIP_EINVAL;
+    cb->variant = variant;
+    return PQHIP_OK;
+}
+
+const char* pqhip_last_encode_kernel(const pqhip_codebook* cb)
+{
+    return cb ? cb->last_kernel.load() : "";
+}
+
+// ---- device-resident entry points -------------------------------------------------------------
+int32_t pqhip_quantize_batch_f32_dev(pqhip_codebook* cb, int32_t slot, const float* d_x, int64_t n,
+                                     int64_t x_rs, void* d_codes, int32_t code_bytes, int64_t o_rs,
+                                     void* stream)
+{
+    if (!cb || n < 0) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
+    if (n > 0 && (!d_x || !d_codes)) return PQHIP_EINVAL;
+    if (code_bytes != 1 && code_bytes != 4) return PQHIP_EUNSUPPORTED;
+    if (code_bytes == 1 && cb->K > 256) return PQHIP_EINDEX_WIDTH;  // primitives.rs:31-34
+    if (n > 0 && (x_rs < cb->d || o_rs < cb->M)) return PQHIP_ESHAPE;
+    HIPCHK(hipSetDevice(cb->ctx->devs[slot]->ordinal));
+    return quantize_dev_impl(cb, slot, d_x, n, x_rs, d_codes, code_bytes, o_rs, (hipStream_t)stream);
+}
+
+int32_t pqhip_reconstruct_batch_f32_dev(pqhip_codebook* cb, int32_t slot, const void* d_codes,
+                                        int32_t code_bytes, int64_t n, int64_t c_rs, float* d_out,
+                                        int64_t o_rs, void* stream)
+{
+    if (!cb || n < 0) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
+    if (n > 0 && (!d_codes || !d_out)) return PQHIP_EINVAL;
+    if (code_bytes != 1 && code_bytes != 4) return PQHIP_EUNSUPPORTED;
+    if (n > 0 && (c_rs < cb->M || o_rs < cb->d)) return PQHIP_ESHAPE;
+    HIPCHK(hipSetDevice(cb->ctx->devs[slot]->ordinal));
+    return reconstruct_dev_impl(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs,
+                                (hipStream_t)stream);
+}
+
+int32_t pqhip_check_codes_dev(pqhip_codebook* cb, int32_t slot, void* stream)
+{
+    if (!cb) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
+    HIPCHK(hipSetDevice(cb->ctx->devs[slot]->ordinal));
+    hipStream_t st = (hipStream_t)stream;
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, cb->dev[slot].err, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(cb->dev[slot].err, 0, sizeof(int), st));
+    HIPCHK(hipStreamSynchronize(st));
+    return flag ? PQHIP_ECODE_RANGE : PQHIP_OK;
+}
+
+// ---- host-resident entry points ---------------------------------------------------------------
+int32_t pqhip_quantize_batch_f32(pqhip_codebook* cb, const float* x, int64_t n, int64_t x_rs,
+                                 int64_t x_cs, void* codes, int32_t code_bytes, int64_t o_rs,
+                                 int64_t o_cs)
+{
+    if (!cb || n < 0) return PQHIP_EINVAL;
+    if (code_bytes != 1 && code_bytes != 2 && code_bytes != 4 && code_bytes != 8) return PQHIP_EINVAL;
+    if (n == 0) return PQHIP_OK;
+    if (!x || !codes) return PQHIP_EINVAL;
+    // primitives.rs:31-34 "Cannot store centroids in quantizer index type"
+    if (code_bytes < 8 && (uint64_t)(cb->K - 1) > ((1ull << (8 * code_bytes)) - 1)) return PQHIP_EINDEX_WIDTH;
+    const int dev_bytes = cb->K <= 256 ? 1 : 4;
+    const int64_t d = cb->d, M = cb->M;
+
+    return for_each_shard(cb->ctx, n, [&](int slot, int64_t rb, int64_t re) -> int32_t {
+        DeviceSlot& ds = *cb->ctx->devs[slot];
+        std::lock_guard<std::mutex> g(ds.mu);
+        HIPCHK(hipSetDevice(ds.ordinal));
+        const int64_t cap = std::min<int64_t>(kStageRows, re - rb);
+        for (int b = 0; b < 2; ++b)
+            PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), (size_t)cap * d * sizeof(float)));
+        auto drain = [&](int b, int64_t r0, int64_t rows) -> int32_t {
+            HIPCHK(hipStreamSynchronize(ds.stream[b]));
+            const uint8_t* h8 = (const uint8_t*)ds.st[b].h_out;
+            const uint32_t* h32 = (const uint32_t*)ds.st[b].h_out;
+            for (int64_t i = 0; i < rows; ++i)
+                for (int64_t m = 0; m < M; ++m) {
+                    const uint32_t v = dev_bytes == 1 ? h8[i * M + m] : h32[i * M + m];
+                    store_code(codes, code_bytes, (r0 + i) * o_rs + m * o_cs, v);
+                }
+            return PQHIP_OK;
+        };
+        int64_t pend_r0[2] = {0, 0}, pend_rows[2] = {0, 0};
+        int b = 0;
+        for (int64_t r0 = rb; r0 < re; r0 += cap, b ^= 1) {
+            const int64_t rows = std::min<int64_t>(cap, re - r0);
+            if (pend_rows[b]) { PQCHK(drain(b, pend_r0[b], pend_rows[b])); pend_rows[b] = 0; }
+            float* hin = (float*)ds.st[b].h_in;
+            if (x_cs == 1) {
+                for (int64_t i = 0; i < rows; ++i)
+                    std::memcpy(hin + i * d, x + (r0 + i) * x_rs, (size_t)d * sizeof(float));
+            } else {
+                for (int64_t i = 0; i < rows; ++i)
+                    for (int64_t k = 0; k < d; ++k) hin[i * d + k] = x[(r0 + i) * x_rs + k * x_cs];
+            }
+            HIPCHK(hipMemcpyAsync(ds.st[b].d_in, hin, (size_t)rows * d * sizeof(float),
+                                  hipMemcpyHostToDevice, ds.stream[b]));
+            PQCHK(quantize_dev_impl(cb, slot, (const float*)ds.st[b].d_in, rows, d, ds.st[b].d_out,
+                                    dev_bytes, M, ds.stream[b]));
+            HIPCHK(hipMemcpyAsync(ds.st[b].h_out, ds.st[b].d_out, (size_t)rows * M * dev_bytes,
+                                  hipMemcpyDeviceToHost, ds.stream[b]));
+            pend_r0[b] = r0; pend_rows[b] = rows;
+        }
+        for (int k = 0; k < 2; ++k)
+            if (pend_rows[k]) PQCHK(drain(k, pend_r0[k], pend_rows[k]));
+        return PQHIP_OK;
+    });
+}
+
+int32_t pqhip_reconstruct_batch_f32(pqhip_codebook* cb, const void* codes, int32_t code_bytes,
+                                    int64_t n, int64_t c_rs, int64_t c_cs, float* out,
+                                    int64_t o_rs, int64_t o_cs)
+{
+    if (!cb || n < 0) return PQHIP_EINVAL;
+    if (code_bytes != 1 && code_bytes != 2 && code_bytes != 4 && code_bytes != 8) return PQHIP_EINVAL;
+    if (n == 0) return PQHIP_OK;
+    if (!codes || !out) return PQHIP_EINVAL;
+    const int dev_bytes = code_bytes == 1 ? 1 : 4;
+    const int64_t d = cb->d, M = cb->M;
+
+    return for_each_shard(cb->ctx, n, [&](int slot, int64_t rb, int64_t re) -> int32_t {
+        DeviceSlot& ds = *cb->ctx->devs[slot];
+        std::lock_guard<std::mutex> g(ds.mu);
+        HIPCHK(hipSetDevice(ds.ordinal));
+        const int64_t cap = std::min<int64_t>(kStageRows, re - rb);
+        for (int b = 0; b < 2; ++b)
+            PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), (size_t)cap * d * sizeof(float)));
+        auto drain = [&](int b, int64_t r0, int64_t rows) -> int32_t {
+            HIPCHK(hipStreamSynchronize(ds.stream[b]));
+            const float* h = (const float*)ds.st[b].h_out;
+            if (o_cs == 1) {
+                for (int64_t i = 0; i < rows; ++i)
+                    std::memcpy(out + (r0 + i) * o_rs, h + i * d, (size_t)d * sizeof(float));
+            } else {
+                for (int64_t i = 0; i < rows; ++i)
+                    for (int64_t k = 0; k < d; ++k) out[(r0 + i) * o_rs + k * o_cs] = h[i * d + k];
+            }
+            return PQHIP_OK;
+        };
+        int64_t pend_r0[2] = {0, 0}, pend_rows[2] = {0, 0};
+        int b = 0;
+        bool range_err = false;
+        for (int64_t r0 = rb; r0 < re; r0 += cap, b ^= 1) {
+            const int64_t rows = std::min<int64_t>(cap, re - r0);
+            if (pend_rows[b]) { PQCHK(drain(b, pend_r0[b], pend_rows[b])); pend_rows[b] = 0; }
+            for (int64_t i = 0; i < rows; ++i)
+                for (int64_t m = 0; m < M; ++m) {
+                    const uint64_t c = load_code(codes, code_bytes, (r0 + i) * c_rs + m * c_cs);
+                    if (c >= (uint64_t)cb->K) range_err = true;  // primitives.rs:146 index_axis panic
+                    if (dev_bytes == 1) ((uint8_t*)ds.st[b].h_in)[i * M + m] = (uint8_t)c;
+                    else ((uint32_t*)ds.st[b].h_in)[i * M + m] = (uint32_t)std::min<uint64_t>(c, 0xffffffffull);
+                }
+            if (range_err) break;
+            HIPCHK(hipMemcpyAsync(ds.st[b].d_in, ds.st[b].h_in, (size_t)rows * M * dev_bytes,
+                                  hipMemcpyHostToDevice, ds.stream[b]));
+            PQCHK(reconstruct_dev_impl(cb, slot, ds.st[b].d_in, dev_bytes, rows, M,
+                                       (float*)ds.st[b].d_out, d, ds.stream[b]));
+            HIPCHK(hipMemcpyAsync(ds.st[b].h_out, ds.st[b].d_out, (size_t)rows * d * sizeof(float),
+                                  hipMemcpyDeviceToHost, ds.stream[b]));
+            pend_r0[b] = r0; pend_rows[b] = rows;
+        }
+        for (int k = 0; k < 2; ++k)
+            if (pend_rows[k]) PQCHK(drain(k, pend_r0[k], pend_rows[k]));
+        return range_err ? PQHIP_ECODE_RANGE : PQHIP_OK;
+    });
+}
+
+int32_t pqhip_selftest_mfma_chain(pqhip_ctx* ctx, int32_t slot, int32_t k, int32_t n_trials,
+                                  uint64_t seed, int64_t* out_mismatches)
+{
+    if (!ctx || !out_mismatches || k <= 0 || n_trials <= 0) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
+    DeviceSlot& ds = *ctx->devs[slot];
+    HIPCHK(hipSetDevice(ds.ordinal));
+    unsigned long long* d_cnt = nullptr;
+    HIPCHK(hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), ds.stream[0]));
+    hipLaunchKernelGGL(k_selftest_mfma_chain, dim3((unsigned)n_trials), dim3(64), 0, ds.stream[0], (int)k,
+                       seed, d_cnt);
+    unsigned long long h = 0;
+    hipError_t e = hipMemcpyAsync(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, ds.stream[0]);
+    if (e == hipSuccess) e = hipStreamSynchronize(ds.stream[0]);
+    (void)hipFree(d_cnt);
+    HIPCHK(e);
+    *out_mismatches = (int64_t)h;
+    return PQHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,366 @@
+"""Host-side mirror of reductive's `Pq<f32>` (src/pq/pq.rs:28-348, src/pq/traits.rs:75-156).
+
+Same names, argument meaning and error behaviour as the reference's `QuantizeVector` /
+`Reconstruct` traits; the batch methods -- the hot path -- dispatch to libpqhip.so through the
+C ABI (include/pqhip.h).  The reference panics on shape errors; here a panic is `PanicError`
+carrying the reference's message.  There is no CPU fallback for the batch methods: without the
+HIP library or a gfx950 device they raise.
+
+The single-vector methods (`quantize_vector`, `reconstruct`) are the reference's latency path
+(pq.rs:285-298, 329-343) and stay on the host, as in the Rust integration.
+"""
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _lib
+
+_INDEX_TYPES = (np.uint8, np.uint16, np.uint32, np.uint64)
+
+
+class PanicError(AssertionError):
+    """A Rust `panic!` / failed `assert!` of the reference surfaced as an exception."""
+
+
+_default_ctx = None
+_ctx_lock = threading.Lock()
+
+
+class _Ctx:
+    def __init__(self, devices=None):
+        L = _lib.lib()
+        h = ctypes.c_void_p()
+        if devices:
+            arr = (ctypes.c_int32 * len(devices))(*devices)
+            rc = L.pqhip_ctx_create(arr, len(devices), ctypes.byref(h))
+        else:
+            rc = L.pqhip_ctx_create(None, 0, ctypes.byref(h))
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_ctx_create")
+        self.handle = h
+        self.devices = list(devices) if devices else None
+        self.n_devices = L.pqhip_ctx_n_devices(h)
+
+    def close(self):
+        if self.handle:
+            _lib.lib().pqhip_ctx_destroy(self.handle)
+            self.handle = None
+
+
+def default_ctx():
+    global _default_ctx
+    with _ctx_lock:
+        if _default_ctx is None:
+            _default_ctx = _Ctx()
+        return _default_ctx
+
+
+def _estrides(a):
+    return [s // a.itemsize for s in a.strides]
+
+
+def _unrolled_dot_rows(a, b):
+    """ndarray numeric_util::unrolled_dot of every row of a [r, n] with b ([n] or [r, n]);
+    float32 with separately rounded multiply and add (numpy never fuses)."""
+    prod = (a * (b if b.ndim == 2 else b[None, :])).astype(np.float32)
+    n = a.shape[1]
+    nf = (n // 8) * 8
+    p = np.zeros((a.shape[0], 8), np.float32)
+    for i in range(0, nf, 8):
+        p = p + prod[:, i:i + 8]
+    s = np.zeros(a.shape[0], np.float32)
+    s = s + (p[:, 0] + p[:, 4])
+    s = s + (p[:, 1] + p[:, 5])
+    s = s + (p[:, 2] + p[:, 6])
+    s = s + (p[:, 3] + p[:, 7])
+    for i in range(nf, n):
+        s = s + prod[:, i]
+    return s
+
+
+def _first_min(d):
+    """kmeans.rs:119-125: first minimum under ordered-float (NaN greatest, -0 == +0)."""
+    ok = ~np.isnan(d)
+    if not ok.any():
+        return 0
+    return int(np.flatnonzero(ok & (d == d[ok].min()))[0])
+
+
+class Pq:
+    """Product quantizer (Jegou et al., 2011) -- mirror of `reductive::pq::Pq<f32>`."""
+
+    def __init__(self, projection, quantizers, ctx=None):
+        """`Pq::new(projection, quantizers)` (pq.rs:38-61)."""
+        quantizers = np.ascontiguousarray(quantizers, dtype=np.float32)
+        if quantizers.ndim != 3 or quantizers.size == 0:
+            raise PanicError("Attempted to construct a product quantizer without quantizers.")
+        rl = quantizers.shape[0] * quantizers.shape[2]
+        if projection is not None:
+            projection = np.ascontiguousarray(projection, dtype=np.float32)
+            if list(projection.shape) != [rl, rl]:
+                raise PanicError("Incorrect projection matrix shape, was: %s, should be [%d, %d]"
+                                 % (list(projection.shape), rl, rl))
+        self._projection = projection
+        self._quantizers = quantizers
+        self._ctx = ctx
+        self._handle = None
+        self._lock = threading.Lock()
+
+    # ---- accessors (pq.rs:103-110, 191-193) -------------------------------------------------
+    def n_quantizer_centroids(self):
+        return self._quantizers.shape[1]
+
+    def projection(self):
+        return self._projection
+
+    def subquantizers(self):
+        return self._quantizers
+
+    def quantized_len(self):
+        return self._quantizers.shape[0]
+
+    def reconstructed_len(self):
+        return self._quantizers.shape[0] * self._quantizers.shape[2]
+
+    def __eq__(self, other):  # #[derive(PartialEq)] pq.rs:28 -- value equality, handle excluded
+        if not isinstance(other, Pq):
+            return NotImplemented
+        pe = (self._projection is None) == (other._projection is None)
+        if pe and self._projection is not None:
+            pe = np.array_equal(self._projection, other._projection)
+        return pe and np.array_equal(self._quantizers, other._quantizers)
+
+    # ---- device handle (created lazily, cached; SURVEY.md section 8b "Ownership") -------------
+    def _cb(self):
+        with self._lock:
+            if self._handle is None:
+                L = _lib.lib()
+                ctx = self._ctx or default_ctx()
+                M, K, dsub = self._quantizers.shape
+                fp = ctypes.POINTER(ctypes.c_float)
+                h = ctypes.c_void_p()
+                proj = self._projection.ctypes.data_as(fp) if self._projection is not None else None
+                rc = L.pqhip_codebook_create(ctx.handle, self._quantizers.ctypes.data_as(fp), M, K,
+                                             dsub, proj, ctypes.byref(h))
+                if rc != _lib.OK:
+                    raise _lib.PqHipError(rc, "pqhip_codebook_create")
+                self._handle = h
+                self._ctx = ctx
+            return self._handle
+
+    def close(self):
+        with self._lock:
+            if self._handle is not None:
+                _lib.lib().pqhip_codebook_destroy(self._handle)
+                self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_encode_variant(self, variant):
+        """test/bench knob: 0 auto, 1 scalar anchor kernel, 2 MFMA kernel."""
+        rc = _lib.lib().pqhip_set_encode_variant(self._cb(), variant)
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc)
+
+    def last_encode_kernel(self):
+        return _lib.lib().pqhip_last_encode_kernel(self._cb()).decode()
+
+    # ---- QuantizeVector (traits.rs:75-99) -----------------------------------------------------
+    def quantize_batch(self, x, dtype=np.uint8):
+        """`quantize_batch::<I, _>(x)` (pq.rs:256-265); `dtype` plays the role of `I`."""
+        x = np.asarray(x, dtype=np.float32)
+        if x.ndim != 2:
+            raise PanicError("quantize_batch expects a matrix")
+        quantized = np.zeros((x.shape[0], self.quantized_len()), dtype=dtype)
+        self.quantize_batch_into(x, quantized)
+        return quantized
+
+    def quantize_batch_into(self, x, quantized):
+        """`quantize_batch_into` (pq.rs:268-283 -> primitives.rs:64-104) on the GPU."""
+        x = np.asarray(x, dtype=np.float32)
+        if quantized.dtype.type not in _INDEX_TYPES:
+            raise TypeError("index type must be one of u8/u16/u32/u64")
+        if x.ndim != 2 or x.shape[1] != self.reconstructed_len():
+            raise PanicError("Quantizer and vector length mismatch")            # primitives.rs:74-78
+        if quantized.shape != (x.shape[0], self.quantized_len()):
+            raise PanicError("Quantized matrix has incorrect shape, expected: (%d, %d), got: (%d, %d)"
+                             % (x.shape[0], self.quantized_len(), quantized.shape[0],
+                                quantized.shape[1] if quantized.ndim > 1 else 0))  # primitives.rs:80-87
+        if x.shape[0] == 0:
+            return
+        if any(s < 0 for s in x.strides) or any(s % 4 for s in x.strides):
+            x = np.ascontiguousarray(x)
+        if any(s < 0 for s in quantized.strides):
+            raise ValueError("negative output strides are not supported")
+        rs, cs = _estrides(x)
+        ors, ocs = _estrides(quantized)
+        rc = _lib.lib().pqhip_quantize_batch_f32(self._cb(), x.ctypes.data, x.shape[0], rs, cs,
+                                                quantized.ctypes.data, quantized.itemsize, ors, ocs)
+        if rc == _lib.EINDEX_WIDTH:
+            # the batch path of the reference has no such assert (it silently wraps,
+            # primitives.rs:98-100); the GPU entry point refuses instead -- see DESIGN.md
+            raise PanicError("Cannot store centroids in quantizer index type")
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_quantize_batch_f32")
+
+    def quantize_vector(self, x, dtype=np.uint8):
+        """`quantize_vector` (pq.rs:285-298 -> primitives.rs:14-49 -> linalg.rs:118-148); host."""
+        x = np.asarray(x, dtype=np.float32)
+        if x.ndim != 1 or x.shape[0] != self.reconstructed_len():
+            raise PanicError("Quantizer and vector length mismatch")            # primitives.rs:25-29
+        K = self.n_quantizer_centroids()
+        if K - 1 > np.iinfo(dtype).max:
+            raise PanicError("Cannot store centroids in quantizer index type")  # primitives.rs:31-34
+        if self._projection is not None:
+            # 1-D x 2-D ndarray dot without BLAS: sequential  s = s + x[k]*P[k,c]  per column
+            rx = np.zeros(x.shape[0], np.float32)
+            for k in range(x.shape[0]):
+                rx = rx + x[k] * self._projection[k]
+            x = rx
+        M, _, dsub = self._quantizers.shape
+        out = np.zeros(M, dtype=dtype)
+        with np.errstate(invalid="ignore", over="ignore"):
+            for m in range(M):
+                xs = x[m * dsub:(m + 1) * dsub]
+                c = self._quantizers[m]
+                xx = _unrolled_dot_rows(xs[None, :], xs)[0]
+                cc = _unrolled_dot_rows(c, c)
+                dp = _unrolled_dot_rows(c, xs)
+                d = (xx + cc) - (dp + dp)
+                out[m] = _first_min(d.astype(np.float32))
+        return out
+
+    # ---- Reconstruct (traits.rs:102-156) ------------------------------------------------------
+    def reconstruct_batch(self, quantized):
+        """`reconstruct_batch` default method (traits.rs:109-117)."""
+        quantized = np.asarray(quantized)
+        if quantized.ndim != 2:
+            raise PanicError("reconstruct_batch expects a matrix")
+        out = np.zeros((quantized.shape[0], self.reconstructed_len()), np.float32)
+        self.reconstruct_batch_into(quantized, out)
+        return out
+
+    def reconstruct_batch_into(self, quantized, reconstructions):
+        """`reconstruct_batch_into` (pq.rs:309-327 -> primitives.rs:150-173) on the GPU."""
+        quantized = np.asarray(quantized)
+        if quantized.dtype.kind == "i":
+            if (quantized < 0).any():
+                raise PanicError("negative code")
+            quantized = quantized.astype(np.uint64)
+        if quantized.dtype.type not in _INDEX_TYPES:
+            raise TypeError("index type must be one of u8/u16/u32/u64")
+        if reconstructions.dtype != np.float32:
+            raise TypeError("reconstructions must be float32")
+        if (quantized.ndim != 2 or reconstructions.ndim != 2
+                or reconstructions.shape[0] != quantized.shape[0]
+                or reconstructions.shape[1] != self.reconstructed_len()):
+            raise PanicError("Reconstructions matrix has incorrect shape, expected: (%d, %d), got: (%d, %d)"
+                             % (quantized.shape[0], self.reconstructed_len(),
+                                reconstructions.shape[0], reconstructions.shape[-1]))  # primitives.rs:159-167
+        if quantized.shape[1] != self.quantized_len():
+            raise PanicError("Quantization length does not match number of subquantizers")  # primitives.rs:123-127
+        if quantized.shape[0] == 0:
+            return
+        if any(s < 0 for s in quantized.strides):
+            quantized = np.ascontiguousarray(quantized)
+        if any(s < 0 for s in reconstructions.strides):
+            raise ValueError("negative output strides are not supported")
+        crs, ccs = _estrides(quantized)
+        ors, ocs = _estrides(reconstructions)
+        rc = _lib.lib().pqhip_reconstruct_batch_f32(self._cb(), quantized.ctypes.data,
+                                                   quantized.itemsize, quantized.shape[0], crs, ccs,
+                                                   reconstructions.ctypes.data, ors, ocs)
+        if rc == _lib.ECODE_RANGE:
+            raise PanicError("ndarray: index out of bounds")                    # primitives.rs:146
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_reconstruct_batch_f32")
+
+    def reconstruct(self, quantized):
+        """`reconstruct` (traits.rs:133-141 -> pq.rs:329-343); single vector, host."""
+        quantized = np.asarray(quantized)
+        if quantized.ndim != 1 or quantized.shape[0] != self.quantized_len():
+            raise PanicError("Quantization length does not match number of subquantizers")
+        K = self.n_quantizer_centroids()
+        if (quantized.astype(np.int64) < 0).any() or (quantized.astype(np.uint64) >= K).any():
+            raise PanicError("ndarray: index out of bounds")
+        rec = np.concatenate([self._quantizers[m, int(c)] for m, c in enumerate(quantized)])
+        if self._projection is not None:
+            # reconstruction.dot(&projection.t()): per output k a contiguous dot with row P[k,:]
+            rec = _unrolled_dot_rows(self._projection, rec.astype(np.float32))
+        return rec.astype(np.float32)
+
+    # ---- device-resident variants (torch tensors in HBM; used by bench.py and the GPU tests) ----
+    def _slot_for(self, tensor):
+        ctx = self._ctx or default_ctx()
+        dev = tensor.device.index or 0
+        if ctx.devices is None:
+            return dev
+        return ctx.devices.index(dev)
+
+    def quantize_batch_device(self, x, out=None, stream=None):
+        """x: CUDA float32 tensor [n, d] (unit column stride) -> uint8 codes tensor [n, M].
+        Asynchronous on torch's current stream unless `stream` (a raw hipStream_t int) is given."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+        if x.shape[1] != self.reconstructed_len():
+            raise PanicError("Quantizer and vector length mismatch")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        if out is None:
+            out = torch.empty((x.shape[0], self.quantized_len()), dtype=torch.uint8, device=x.device)
+        if tuple(out.shape) != (x.shape[0], self.quantized_len()):
+            raise PanicError("Quantized matrix has incorrect shape, expected: (%d, %d), got: (%d, %d)"
+                             % (x.shape[0], self.quantized_len(), out.shape[0], out.shape[1]))
+        assert out.is_cuda and out.dtype == torch.uint8 and out.stride(1) == 1
+        cb = self._cb()
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = _lib.lib().pqhip_quantize_batch_f32_dev(cb, self._slot_for(x), x.data_ptr(), x.shape[0],
+                                                    x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1]),
+                                                    out.data_ptr(), 1,
+                                                    out.stride(0) if out.shape[0] > 1 else max(out.stride(0), out.shape[1]),
+                                                    ctypes.c_void_p(stream))
+        if rc == _lib.EINDEX_WIDTH:
+            raise PanicError("Cannot store centroids in quantizer index type")
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_quantize_batch_f32_dev")
+        return out
+
+    def reconstruct_batch_device(self, codes, out=None, stream=None, check=False):
+        """codes: CUDA uint8 tensor [n, M] -> float32 tensor [n, d]."""
+        import torch
+        assert codes.is_cuda and codes.dtype == torch.uint8 and codes.dim() == 2
+        if codes.shape[1] != self.quantized_len():
+            raise PanicError("Quantization length does not match number of subquantizers")
+        if codes.stride(1) != 1:
+            codes = codes.contiguous()
+        if out is None:
+            out = torch.empty((codes.shape[0], self.reconstructed_len()), dtype=torch.float32,
+                              device=codes.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.stride(1) == 1
+        if tuple(out.shape) != (codes.shape[0], self.reconstructed_len()):
+            raise PanicError("Reconstructions matrix has incorrect shape, expected: (%d, %d), got: (%d, %d)"
+                             % (codes.shape[0], self.reconstructed_len(), out.shape[0], out.shape[1]))
+        cb = self._cb()
+        if stream is None:
+            stream = torch.cuda.current_stream(codes.device).cuda_stream
+        slot = self._slot_for(codes)
+        rc = _lib.lib().pqhip_reconstruct_batch_f32_dev(
+            cb, slot, codes.data_ptr(), 1, codes.shape[0],
+            codes.stride(0) if codes.shape[0] > 1 else max(codes.stride(0), codes.shape[1]),
+            out.data_ptr(), out.stride(0) if out.shape[0] > 1 else max(out.stride(0), out.shape[1]),
+            ctypes.c_void_p(stream))
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_reconstruct_batch_f32_dev")
+        if check:
+            rc = _lib.lib().pqhip_check_codes_dev(cb, slot, ctypes.c_void_p(stream))
+            if rc == _lib.ECODE_RANGE:
+                raise PanicError("ndarray: index out of bounds")
+            if rc != _lib.OK:
+                raise _lib.PqHipError(rc, "pqhip_check_codes_dev")
+        return out

@@ -1,0 +1,329 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+include/pqhip.h (via the `Pq` host mirror), against the CPU oracle and the golden fixtures.
+Bar: codes bit-exact; PQ reconstructions bit-exact; OPQ reconstructions within 1e-5 relative."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import pq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REL_TOL = 1e-5   # north_star: reconstructions agree within 1e-5 relative
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import reductive_amd
+    reductive_amd.lib()          # must load: no fallback
+    return reductive_amd
+
+
+def _pq(ra, q, P=None, variant=0):
+    pq = ra.Pq(P, q)
+    if variant:
+        pq.set_encode_variant(variant)
+    return pq
+
+
+# ---- the hardware property the MFMA path rests on --------------------------------------------
+@pytest.mark.parametrize("k", [2, 7, 16, 20, 300])
+def test_mfma_is_a_k_ordered_fmaf_chain(ra, k):
+    from reductive_amd.pq import default_ctx
+    bad = ctypes.c_int64(-1)
+    rc = ra.lib().pqhip_selftest_mfma_chain(default_ctx().handle, 0, k, 256, 1234 + k,
+                                            ctypes.byref(bad))
+    assert rc == 0, ra.lib().pqhip_last_hip_error()
+    assert bad.value == 0
+
+
+# ---- the reference's own KATs through the GPU path -------------------------------------------
+def test_kat_quantize_and_reconstruct(ra, kats):
+    k = kats["pq_predefined_codebook"]
+    pq = _pq(ra, np.array(k["quantizers"], np.float32))
+    x = np.array(k["vectors"], np.float32)
+    for dt in (np.uint8, np.uint16, np.uint32, np.uint64):
+        assert pq.quantize_batch(x, dtype=dt).tolist() == k["quantizations"]
+    rec = pq.reconstruct_batch(np.array(k["quantizations"], np.uint64))
+    assert rec.tolist() == k["reconstructions"]
+    assert pq.reconstruct_batch(np.array(k["quantizations"], np.uint8)).tolist() == k["reconstructions"]
+    assert pq.quantized_len() == k["quantized_len"]
+    assert pq.reconstructed_len() == k["reconstructed_len"]
+
+
+def test_kat_cluster_assignments(ra, kats):
+    k = kats["cluster_assignments"]
+    c = np.array(k["centroids"], np.float32)
+    x = np.array(k["instances"], np.float32)
+    pq = _pq(ra, c[None])
+    assert pq.quantize_batch(x)[:, 0].tolist() == k["assignments"]
+    assert pq.quantize_batch(np.asfortranarray(x))[:, 0].tolist() == k["assignments"]  # kmeans.rs:397-399
+
+
+# ---- golden fixtures --------------------------------------------------------------------------
+def _golden_cases():
+    with open(os.path.join(GOLD, "cases.json")) as f:
+        return sorted(json.load(f).keys())
+
+
+@pytest.mark.parametrize("name", _golden_cases())
+def test_golden_fixture(ra, name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    meta = json.load(open(os.path.join(GOLD, "cases.json")))[name]
+    data = np.load(os.path.join(GOLD, "cases.npz"))
+    q, x, opq, _ = mg.make_inputs(name)
+    assert synth.sha(q) == meta["sha_q"] and synth.sha(x) == meta["sha_x"]
+    P = data[name + "/projection"] if opq else None
+    want = data[name + "/codes"]
+    pq = _pq(ra, q, P)
+    got = pq.quantize_batch(x)
+    assert got.tobytes() == want.tobytes()
+    rec = pq.reconstruct_batch(want)
+    if opq:
+        ref = orc.reconstruct_batch(q, want, projection=P)
+        assert np.abs(rec - ref).max() <= REL_TOL * np.abs(ref).max()
+    else:
+        assert synth.sha(rec) == meta["sha_rec"]
+
+
+# ---- seeded parity against the oracle, both kernels -------------------------------------------
+SHAPES = [  # n, M, K, dsub
+    (4113, 15, 256, 20),    # headline shape, ragged n
+    (1000, 48, 256, 16),    # d=768 shape
+    (999, 10, 128, 2),      # pq.rs:435-436 shape
+    (500, 16, 16, 8),       # benches/pq.rs shape
+    (300, 5, 40, 7),        # odd dsub, K not a multiple of 32
+    (257, 3, 200, 32),      # largest resident fragment set
+    (100, 4, 300, 6),       # K > 256 -> wider index type, anchor kernel
+    (64, 2, 64, 40),        # dsub > 32 -> anchor kernel
+    (33, 1, 1, 5),          # K = 1
+    (1, 15, 256, 20),       # single row
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_encode_matches_oracle(ra, shape, variant):
+    n, M, K, dsub = shape
+    q = synth.normalish(100 + n, (M, K, dsub))
+    x = synth.normalish(200 + n, (n, M * dsub))
+    dt = np.uint8 if K <= 256 else np.uint16
+    want = orc.quantize_batch(q, x, dtype=dt)
+    pq = _pq(ra, q, variant=variant)
+    got = pq.quantize_batch(x, dtype=dt)
+    assert got.tobytes() == want.tobytes()
+    if variant == 0 and K <= 256 and dsub <= 32:
+        assert pq.last_encode_kernel().startswith("k_encode_mfma")
+
+
+def test_encode_special_values(ra):
+    M, K, dsub = 4, 64, 8
+    q = synth.normalish(31, (M, K, dsub))
+    x = synth.normalish(32, (200, M * dsub))
+    x[3, 1] = np.nan
+    x[50, 9] = np.inf
+    x[51, 17] = -np.inf
+    x[100] = 0
+    x[101] = -0.0
+    x[150] *= np.float32(1e19)          # xx ~ 1e38 .. overflow region
+    x[151] *= np.float32(3e19)          # xx overflows to inf
+    x[160] *= np.float32(1e-30)         # subnormal products
+    want = orc.quantize_batch(q, x)
+    for variant in (0, 1):
+        got = _pq(ra, q, variant=variant).quantize_batch(x)
+        assert got.tobytes() == want.tobytes(), variant
+    # NaN / Inf / huge centroids: codebook leaves the fast path entirely
+    q2 = q.copy()
+    q2[0, 5, 2] = np.nan
+    q2[1, 7, 0] = np.inf
+    q2[2, 9] *= np.float32(1e19)
+    want2 = orc.quantize_batch(q2, x)
+    assert _pq(ra, q2).quantize_batch(x).tobytes() == want2.tobytes()
+
+
+def test_encode_exact_and_near_ties(ra):
+    M, K, dsub = 2, 64, 4
+    q = synth.normalish(41, (M, K, dsub))
+    q[0, 40] = q[0, 7]                   # exact duplicates: lowest index must win
+    q[1, 63] = q[1, 0]
+    x = synth.normalish(42, (512, M * dsub))
+    x[:64, :dsub] = q[0, 7]              # rows sitting exactly on the duplicated centroid
+    x[64:128, dsub:] = q[1, 63]
+    mid = (q[0, 3] + q[0, 4]) / 2        # midpoints, nudged by single ulps
+    for i in range(128, 192):
+        x[i, :dsub] = np.nextafter(mid, np.float32(np.inf if i % 2 else -np.inf))
+    big = synth.normalish(43, (64, dsub)) * np.float32(4096)   # |x|^2 >> |c|^2: rounding ties
+    x[192:256, :dsub] = big
+    want = orc.quantize_batch(q, x)
+    assert (want[:64, 0] == 7).all() and (want[64:128, 1] == 0).all()
+    for variant in (0, 1):
+        assert _pq(ra, q, variant=variant).quantize_batch(x).tobytes() == want.tobytes()
+
+
+def test_reconstruct_exact_and_range_check(ra):
+    M, K, dsub = 15, 256, 20
+    q = synth.normalish(51, (M, K, dsub))
+    codes = synth.codes_u8(52, (3001, M), K)
+    pq = _pq(ra, q)
+    rec = pq.reconstruct_batch(codes)
+    assert rec.tobytes() == orc.reconstruct_batch(q, codes).tobytes()
+    assert pq.reconstruct_batch(codes.astype(np.uint32)).tobytes() == rec.tobytes()
+    # odd sub-dimension: scalar store path
+    q2 = synth.normalish(53, (5, 40, 7))
+    c2 = synth.codes_u8(54, (100, 5), 40)
+    assert _pq(ra, q2).reconstruct_batch(c2).tobytes() == orc.reconstruct_batch(q2, c2).tobytes()
+    bad = c2.copy()
+    bad[77, 3] = 40
+    with pytest.raises(ra.PanicError):
+        _pq(ra, q2).reconstruct_batch(bad)
+
+
+def test_opq_rotate_encode_and_reconstruct(ra):
+    for (n, M, K, dsub) in [(700, 15, 256, 20), (300, 8, 64, 8), (65, 3, 16, 5)]:
+        d = M * dsub
+        q = synth.normalish(61 + d, (M, K, dsub))
+        x = synth.normalish(62 + d, (n, d))
+        P = synth.orthonormal(63 + d, d)
+        want = orc.quantize_batch(q, x, projection=P)
+        pq = _pq(ra, q, P)
+        got = pq.quantize_batch(x)
+        assert got.tobytes() == want.tobytes()
+        ref = orc.reconstruct_batch(q, want, projection=P)
+        rec = pq.reconstruct_batch(want)
+        assert np.abs(rec - ref).max() <= REL_TOL * np.abs(ref).max()
+        assert rec.tobytes() == ref.tobytes()      # stronger than required: same chain rule
+
+
+def test_strided_host_buffers(ra):
+    M, K, dsub = 3, 32, 4
+    q = synth.normalish(71, (M, K, dsub))
+    big = synth.normalish(72, (40, 40))
+    x = big[::2, 5:17]
+    want = orc.quantize_batch(q, np.ascontiguousarray(x))
+    pq = _pq(ra, q)
+    assert pq.quantize_batch(x).tolist() == want.tolist()
+    assert pq.quantize_batch(np.asfortranarray(x)).tolist() == want.tolist()
+    out = np.zeros((M, x.shape[0]), np.uint16).T
+    pq.quantize_batch_into(x, out)
+    assert out.tolist() == want.tolist()
+    rec = np.zeros((x.shape[0], 2 * M * dsub), np.float32)[:, ::2]
+    pq.reconstruct_batch_into(want, rec)
+    assert rec.tolist() == orc.reconstruct_batch(q, want).tolist()
+
+
+def test_empty_batch(ra):
+    q = synth.normalish(81, (2, 4, 3))
+    pq = _pq(ra, q)
+    assert pq.quantize_batch(np.zeros((0, 6), np.float32)).shape == (0, 2)
+    assert pq.reconstruct_batch(np.zeros((0, 2), np.uint8)).shape == (0, 6)
+
+
+def test_row_sharding_over_two_device_slots(ra):
+    """SURVEY.md 8e on one GPU: a ctx with two slots on device 0 shards rows across two host
+    threads exactly as it would across two GPUs (no collective; disjoint output ranges)."""
+    from reductive_amd.pq import _Ctx
+    ctx = _Ctx(devices=[0, 0])
+    try:
+        assert ctx.n_devices == 2
+        M, K, dsub = 15, 256, 20
+        q = synth.normalish(91, (M, K, dsub))
+        x = synth.normalish(92, (20001, M * dsub))
+        pq = ra.Pq(None, q, ctx=ctx)
+        want = orc.quantize_batch(q, x, n_threads=8)
+        assert pq.quantize_batch(x).tobytes() == want.tobytes()
+        assert pq.reconstruct_batch(want).tobytes() == orc.reconstruct_batch(q, want).tobytes()
+        pq.close()
+    finally:
+        ctx.close()
+
+
+def test_concurrent_callers(ra):
+    """`Pq<f32>` is Send + Sync in the reference: concurrent quantize_batch calls must work."""
+    import threading
+    M, K, dsub = 8, 64, 8
+    q = synth.normalish(95, (M, K, dsub))
+    pq = _pq(ra, q)
+    xs = [synth.normalish(96 + i, (3000 + i, M * dsub)) for i in range(4)]
+    wants = [orc.quantize_batch(q, x) for x in xs]
+    got = [None] * 4
+
+    def run(i):
+        got[i] = pq.quantize_batch(xs[i])
+    th = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for g, w in zip(got, wants):
+        assert g.tobytes() == w.tobytes()
+
+
+# ---- device-resident path (what bench.py times) + size-independent properties ------------------
+def test_device_resident_and_properties_at_scale(ra):
+    import torch
+    M, K, dsub = 15, 256, 20
+    n = 2_000_000
+    q = synth.normalish(101, (M, K, dsub))
+    pq = _pq(ra, q)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn((n, M * dsub), device="cuda", dtype=torch.float32, generator=g)
+    codes = pq.quantize_batch_device(x)
+    torch.cuda.synchronize()
+    assert pq.last_encode_kernel() == "k_encode_mfma<vec4>"
+    # (1) sampled rows against the oracle: first / last 32k rows + a strided sample
+    idx = torch.cat([torch.arange(0, 32768), torch.arange(n - 32768, n),
+                     torch.arange(0, n, 97)]).cuda()
+    want = orc.quantize_batch(q, x[idx].cpu().numpy(), n_threads=8)
+    assert codes[idx].cpu().numpy().tobytes() == want.tobytes()
+    # (2) both kernels agree on a 200k slice
+    pq1 = _pq(ra, q, variant=1)
+    c1 = pq1.quantize_batch_device(x[:200_000])
+    assert torch.equal(c1, codes[:200_000])
+    # (3) decode -> encode is the identity on codes (random codebook has no duplicate rows)
+    rec = pq.reconstruct_batch_device(codes, check=True)
+    again = pq.quantize_batch_device(rec)
+    assert torch.equal(again, codes)
+    # (4) reconstruct is a gather: checksum of rows == checksum of gathered codebook rows
+    qt = torch.from_numpy(q).cuda()
+    s_ref = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for m in range(M):
+        s_ref += qt[m].double().sum(1)[codes[:, m].long()]
+    assert torch.allclose(rec.double().sum(1), s_ref, rtol=0, atol=1e-9)
+    # (5) row-strided device input (a column window of a wider matrix)
+    wide = torch.randn((5000, 2 * M * dsub + 4), device="cuda", generator=g)
+    view = wide[:, 4:4 + M * dsub]
+    assert torch.equal(pq.quantize_batch_device(view), pq.quantize_batch_device(view.contiguous()))
+    # (6) out-of-range code is reported on the device path
+    q2 = synth.normalish(102, (4, 40, 8))
+    pq2 = _pq(ra, q2)
+    bad = torch.full((10, 4), 40, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ra.PanicError):
+        pq2.reconstruct_batch_device(bad, check=True)
+
+
+def test_statistical_roundtrip_loss(ra, kats):
+    """pq.rs:431-440 analogue: a trained 7-bit quantizer on U[0,1) 256x20 reconstructs with mean
+    Euclidean loss < 0.08 (training itself is out of scope: a few Lloyd steps in numpy)."""
+    st = kats["statistical"]
+    n, d, M, K = st["n"], st["d"], st["n_subquantizers"], 1 << st["n_bits"]
+    dsub = d // M
+    x = synth.uniform01(111, (n, d))
+    q = np.stack([x[synth.codes_u8(112 + m, (K,), 255).astype(int) % n, m * dsub:(m + 1) * dsub]
+                  for m in range(M)]).astype(np.float32)
+    for _ in range(10):
+        codes = orc.quantize_batch(q, x)
+        for m in range(M):
+            for j in range(K):
+                sel = codes[:, m] == j
+                if sel.any():
+                    q[m, j] = x[sel, m * dsub:(m + 1) * dsub].mean(0)
+    pq = _pq(ra, q)
+    rec = pq.reconstruct_batch(pq.quantize_batch(x))
+    loss = np.sqrt(((x - rec) ** 2).sum(1)).mean()
+    assert loss < st["loss_bound"]
