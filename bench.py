@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement: vectors/s of Pq::quantize_batch (d=300, M=15, K=256) on
+MI355X, inputs resident in HBM, through the C ABI of libpqhip.so.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: rows_per_gpu synthetic fp32 vectors already
+in HBM -> u8 codes in HBM.  With N > 1 every rank owns an independent row shard (the path has no
+exchange step: no collective on the data path, "weak" scaling); the only collectives are the
+barrier and the max-reduction of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+D, M, K = 300, 15, 256            # BASELINE.json metric: d=300, M=15, K=256
+DSUB = D // M
+FLOP_PER_VEC = 2 * K * D          # distance GEMM only: 153,600
+BYTES_PER_VEC = 4 * D + M         # algorithmic HBM bytes per vector: 1,215
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+
+WORKLOADS = {
+    "encode": "Pq::quantize_batch 10M x d=300 fp32, M=15, K=256 on 1 MI355X (BASELINE configs[1])",
+    "opq_encode": "Opq rotate+encode 10M x d=300, M=15, K=256 (BASELINE configs[2])",
+    "reconstruct": "Pq::reconstruct_batch u8 codes -> d=300 fp32 (BASELINE configs[3])",
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="encode")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 anchor kernel, 2 MFMA kernel")
+    ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise sharding/reduction/printing only (CPU, gloo); no GPU work")
+    return ap.parse_args()
+
+
+def shard_ranges(world, rows):
+    """weak scaling: rank r owns global rows [r*rows, (r+1)*rows)."""
+    return [[r * rows, (r + 1) * rows] for r in range(world)]
+
+
+def load_pmc_traffic(workload, rows):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if they were
+    collected for exactly this workload size; else None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(p)).get(workload)
+        if rec and int(rec["rows"]) == rows:
+            return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = not args.dry_run
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    rows = args.rows
+    shards = shard_ranges(world, rows)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    kernel_ms = None
+    extra = {}
+    if use_gpu:
+        import numpy as np
+        import reductive_amd
+        import synth
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        reductive_amd.lib()                       # fails loudly if the HIP library is missing
+        from reductive_amd.pq import _Ctx
+        ctx = _Ctx(devices=[local_rank])          # one process per GPU
+        q = synth.normalish(43, (M, K, DSUB))     # same codebook on every rank (replicated)
+        P = synth.orthonormal(44, D) if args.workload == "opq_encode" else None
+        pq = reductive_amd.Pq(P, q, ctx=ctx)
+        if args.variant:
+            pq.set_encode_variant(args.variant)
+        g = torch.Generator(device=dev).manual_seed(42 + rank)
+        if args.workload == "reconstruct":
+            src = torch.randint(0, K, (rows, M), device=dev, dtype=torch.uint8, generator=g)
+            dst = torch.empty((rows, D), device=dev, dtype=torch.float32)
+
+            def step():
+                pq.reconstruct_batch_device(src, out=dst)
+        else:
+            src = torch.empty((rows, D), device=dev, dtype=torch.float32)
+            for r0 in range(0, rows, 1 << 20):    # N(0,1) like benches/pq.rs:9, generated in HBM
+                src[r0:r0 + (1 << 20)].normal_(generator=g)
+            dst = torch.empty((rows, M), device=dev, dtype=torch.uint8)
+
+            def step():
+                pq.quantize_batch_device(src, out=dst)
+        for _ in range(args.warmup):
+            step()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()                            # same stream the kernels are launched on
+            step()
+            b.record()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        extra["encode_kernel"] = pq.last_encode_kernel() if args.workload != "reconstruct" else "k_reconstruct"
+    else:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.001)
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if (use_gpu and world > 1) else "cpu")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        total_rows = world * rows
+        value = total_rows * args.steps / elapsed
+        names = {"encode": "vectors/sec PQ encode (d=300, M=15, K=256)",
+                 "opq_encode": "vectors/sec OPQ rotate+encode (d=300, M=15, K=256)",
+                 "reconstruct": "vectors/sec PQ reconstruct (d=300, M=15, K=256)"}
+        rec = {
+            "metric": names[args.workload], "value": value, "unit": "vectors/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload], "rows_per_gpu": rows,
+                       "rows_total": total_rows, "d": D, "M": M, "K": K, "shards": shards,
+                       "placement": "inputs and outputs resident in HBM; C ABI device entry point"},
+        }
+        rec.update(extra)
+        if use_gpu:
+            sec = kernel_ms * 1e-3
+            traffic = load_pmc_traffic(args.workload, rows)
+            if args.workload == "reconstruct":
+                ach = BYTES_PER_VEC * rows / sec / 1e9
+                rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
+                                   "kernel": "k_reconstruct", "avg_launch_ms": kernel_ms,
+                                   "algorithmic_bytes_per_vector": BYTES_PER_VEC}
+            else:
+                flop = FLOP_PER_VEC + (2 * D * D if args.workload == "opq_encode" else 0)
+                ach = flop * rows / sec / 1e12
+                rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                                   "kernel": "k_encode_mfma" if args.workload == "encode" else "k_rotate_mfma+k_encode_mfma",
+                                   "avg_launch_ms": kernel_ms, "algorithmic_flop_per_vector": flop,
+                                   "algorithmic_bytes_per_vector": BYTES_PER_VEC,
+                                   "hbm_gbs": BYTES_PER_VEC * rows / sec / 1e9,
+                                   "hbm_frac": BYTES_PER_VEC * rows / sec / 1e9 / PEAK_HBM_GBS}
+            if world == 1 and not args.no_cpu_baseline and args.workload != "reconstruct":
+                rec["cpu_baseline"] = cpu_baseline(args, q, P, src, dst, pq)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, q, P, src, dst, pq):
+    """The oracle (a C port of the reference's path, CANON-F32) timed on this box's host cores on
+    a bounded sample of the SAME workload, plus a parity check of the GPU codes on that sample.
+    The oracle is used here only as the thing timed/checked -- never as the product."""
+    from oracle import pq_oracle as orc
+    cores = os.cpu_count() or 1
+    n_mt = min(args.cpu_rows, src.shape[0])
+    n_st = min(max(n_mt // 8, 1), 250_000)
+    x = src[:n_mt].cpu().numpy()
+    t = time.perf_counter()
+    c_mt = orc.quantize_batch(q, x, projection=P, n_threads=cores)
+    t_mt = time.perf_counter() - t
+    t = time.perf_counter()
+    orc.quantize_batch(q, x[:n_st], projection=P, n_threads=1)
+    t_st = time.perf_counter() - t
+    same = bool((dst[:n_mt].cpu().numpy() == c_mt).all())
+    # PCIe-inclusive rate of the host-buffer entry point on the same sample (never `value`)
+    n_h = min(n_mt, 1_000_000)
+    pq.quantize_batch(x[:65536])
+    t = time.perf_counter()
+    c_h = pq.quantize_batch(x[:n_h])
+    t_h = time.perf_counter() - t
+    return {"value": n_mt / t_mt, "unit": "vectors/s", "cores": cores, "kind": "port",
+            "sample": "first %d rows of the bench batch, oracle sharded over %d threads (%.1f s); "
+                      "single-thread: %d rows" % (n_mt, cores, t_mt, n_st),
+            "single_thread_value": n_st / t_st, "simd": "avx2+fma" if orc.lib().pqo_uses_fma_simd() else "scalar",
+            "gpu_codes_identical_on_sample": same,
+            "host_resident_api_value": n_h / t_h,
+            "host_resident_api_identical": bool((c_h == c_mt[:n_h]).all())}
+
+
+if __name__ == "__main__":
+    main()

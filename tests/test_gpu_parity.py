@@ -314,7 +314,9 @@ def test_statistical_roundtrip_loss(ra, kats):
     n, d, M, K = st["n"], st["d"], st["n_subquantizers"], 1 << st["n_bits"]
     dsub = d // M
     x = synth.uniform01(111, (n, d))
-    q = np.stack([x[synth.codes_u8(112 + m, (K,), 255).astype(int) % n, m * dsub:(m + 1) * dsub]
+    # random-instance initialisation with K DISTINCT rows (kmeans.rs:52-87)
+    q = np.stack([x[np.argsort(synth.splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(977 * m)),
+                               kind="stable")[:K], m * dsub:(m + 1) * dsub]
                   for m in range(M)]).astype(np.float32)
     for _ in range(10):
         codes = orc.quantize_batch(q, x)
