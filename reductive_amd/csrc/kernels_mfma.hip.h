@@ -138,59 +138,85 @@ __global__ __launch_bounds__(256, 2) void k_encode_mfma(EncodeArgs a)
         }
     };
 
-    float v[DP];
-    load_tile(v, row_begin);
-
-    for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
-        float vn[DP];
-        const int64_t next0 = (row0 + 32 < row_end) ? row0 + 32 : row0;
-        load_tile(vn, next0);  // prefetch (re-reads the last tile once at the end; harmless)
-
-        const float xx = norm_unrolled_padded<DP>(v, dsub);
-        float bop[S];
+    // operands of one 32-row tile: B fragments (k = 2s + h of the lane's row) and ||x||^2
+    auto prep_tile = [&](const float (&v)[DP], float (&bop)[S], float& xx) {
+        xx = norm_unrolled_padded<DP>(v, dsub);
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = h ? v[2 * s + 1] : v[2 * s];
+    };
+    auto chain = [&](int t, const float (&bop)[S]) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                      0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][s], bop[s], acc, 0, 0, 0);
+        return acc;
+    };
+
+    // ---- software pipeline over steps (x tile i, centroid tile t) ----
+    // While the VALU turns the 16 distances of step (i, t) into a running (min, argmin), the
+    // matrix core already runs the fmaf chains of step (i, t+1) -- or of (i+1, 0) at the seam --
+    // into a second accumulator set; sched_group_barrier pins the 1-MFMA : 8-VALU interleave.
+    const int64_t last_tile0 = row_begin + ((row_end - row_begin - 1) / 32) * 32;
+    float vn[DP];
+    float bop[S];
+    float xx;
+    load_tile(vn, row_begin);
+    prep_tile(vn, bop, xx);
+    load_tile(vn, (row_begin + 32 <= last_tile0) ? row_begin + 32 : last_tile0);
+    f32x16 acc = chain(0, bop);
+
+    for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
+        float bop_n[S];
+        float xx_n;
+        prep_tile(vn, bop_n, xx_n);  // tile i+1
+        load_tile(vn, (row0 + 64 <= last_tile0) ? row0 + 64 : last_tile0);  // tile i+2, in flight
+
+        float best = __builtin_inff();
+        int bidx = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const f32x16 acc_n = (t + 1 < T) ? chain(t + 1, bop) : chain(0, bop_n);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // ||c||^2 of centroids 32t + 8g + 4h + {0,1,2,3}: one ds_read_b128
+                const f32x4 c4 =
+                    *reinterpret_cast<const f32x4*>(&cc_s[wave][32 * t + 8 * g + 4 * h]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float tt = fadd(xx, c4[q]);
+                    // == fl(tt - fl(dp + dp)): 2*dp is exact and cannot overflow here
+                    const float d = ffma(acc[4 * g + q], -2.0f, tt);
+                    const bool lt = d < best;
+                    best = lt ? d : best;
+                    bidx = lt ? (32 * t + 8 * g + q) : bidx;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
+                if (s < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x002, (80 + S - 1) / S, 0);  // VALU share
+            }
+            acc = acc_n;
+        }
+        bidx += 4 * h;
+        // merge the two half-waves: lexicographic (distance, index) minimum
+        const float od = __shfl_xor(best, 32);
+        const int oi = __shfl_xor(bidx, 32);
+        if (od < best || (od == best && oi < bidx)) bidx = oi;
 
         const int64_t row = row0 + j;
         const bool valid = row < a.n;
-        const bool fast_ok = xx < kBigNorm;  // false for NaN / Inf / huge
-        if (__builtin_amdgcn_ballot_w64(!fast_ok) != 0ull) {
+        // NaN / Inf / huge rows: the fast epilogue's fma shortcut is not valid -> exact slow path
+        if (__builtin_amdgcn_ballot_w64(!(xx < kBigNorm)) != 0ull) {
             encode_tile_slow<IdxT>(a, m, row, valid);
-        } else {
-            float best = __builtin_inff();
-            int bidx = 0;
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
-                              0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < S; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][s], bop[s], acc, 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    // ||c||^2 of centroids 32t + 8g + 4h + {0,1,2,3}: one ds_read_b128
-                    const f32x4 c4 =
-                        *reinterpret_cast<const f32x4*>(&cc_s[wave][32 * t + 8 * g + 4 * h]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float tt = fadd(xx, c4[q]);
-                        // == fl(tt - fl(dp + dp)): 2*dp is exact and cannot overflow here
-                        const float d = ffma(acc[4 * g + q], -2.0f, tt);
-                        const bool lt = d < best;
-                        best = lt ? d : best;
-                        bidx = lt ? (32 * t + 8 * g + q) : bidx;
-                    }
-                }
-            }
-            bidx += 4 * h;
-            // merge the two half-waves: lexicographic (distance, index) minimum
-            const float od = __shfl_xor(best, 32);
-            const int oi = __shfl_xor(bidx, 32);
-            if (od < best || (od == best && oi < bidx)) bidx = oi;
-            if (h == 0 && valid) reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
+        } else if (h == 0 && valid) {
+            reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
         }
 #pragma unroll
-        for (int e = 0; e < DP; ++e) v[e] = vn[e];
+        for (int s = 0; s < S; ++s) bop[s] = bop_n[s];
+        xx = xx_n;
     }
 }
 
