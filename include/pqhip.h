@@ -116,7 +116,8 @@ int32_t pqhip_reconstruct_batch_f32_dev(pqhip_codebook *cb, int32_t device_slot,
 int32_t pqhip_check_codes_dev(pqhip_codebook *cb, int32_t device_slot, void *stream);
 
 /* ---- knobs used by the test-suite and the bench (not part of the reference surface) -------- */
-/* force a kernel variant for encode: 0 = auto, 1 = scalar VALU anchor kernel, 2 = MFMA kernel  */
+/* force a kernel variant for encode: 0 = auto, 1 = scalar VALU anchor kernel,
+ * 2 = MFMA kernel with VALU argmin, 3 = MFMA kernel with LDS-atomic argmin (the auto choice)  */
 int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);
 /* name of the encode kernel the last device call on this codebook launched ("" if none)        */
 const char *pqhip_last_encode_kernel(const pqhip_codebook *cb);

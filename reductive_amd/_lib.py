@@ -29,7 +29,7 @@ def lib_path():
 def build(force=False):
     """Compile libpqhip.so for gfx950 (hipcc cross-compiles without a GPU)."""
     srcdir = os.path.join(_HERE, "csrc")
-    cmd = ["make", "-C", srcdir, "-s"]
+    cmd = ["make", "-C", srcdir, "-s", "-j8"]
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd)

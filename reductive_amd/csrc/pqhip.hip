@@ -21,6 +21,8 @@
 
 #include "kernels_basic.hip.h"
 #include "kernels_mfma.hip.h"
+#include "kernels_rotate.hip.h"
+#include "encode_launch.h"
 
 using namespace pqhip;
 
@@ -127,44 +129,6 @@ void free_staging(Staging& s)
     s = Staging();
 }
 
-// ---- MFMA encode dispatch ------------------------------------------------------------------
-template <int T, int DP, typename IdxT>
-void launch_encode_mfma_vec(bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
-{
-    if (vec)
-        hipLaunchKernelGGL((k_encode_mfma<T, DP, true, IdxT>), grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((k_encode_mfma<T, DP, false, IdxT>), grid, dim3(256), 0, st, a);
-}
-
-template <int T, typename IdxT>
-bool launch_encode_mfma_dp(int DP, bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
-{
-    switch (DP) {
-    case 4: launch_encode_mfma_vec<T, 4, IdxT>(vec, a, grid, st); return true;
-    case 8: launch_encode_mfma_vec<T, 8, IdxT>(vec, a, grid, st); return true;
-    case 12: launch_encode_mfma_vec<T, 12, IdxT>(vec, a, grid, st); return true;
-    case 16: launch_encode_mfma_vec<T, 16, IdxT>(vec, a, grid, st); return true;
-    case 20: launch_encode_mfma_vec<T, 20, IdxT>(vec, a, grid, st); return true;
-    case 24: launch_encode_mfma_vec<T, 24, IdxT>(vec, a, grid, st); return true;
-    case 28: launch_encode_mfma_vec<T, 28, IdxT>(vec, a, grid, st); return true;
-    case 32: launch_encode_mfma_vec<T, 32, IdxT>(vec, a, grid, st); return true;
-    default: return false;
-    }
-}
-
-template <typename IdxT>
-bool launch_encode_mfma(int T, int DP, bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
-{
-    switch (T) {
-    case 1: return launch_encode_mfma_dp<1, IdxT>(DP, vec, a, grid, st);
-    case 2: return launch_encode_mfma_dp<2, IdxT>(DP, vec, a, grid, st);
-    case 4: return launch_encode_mfma_dp<4, IdxT>(DP, vec, a, grid, st);
-    case 8: return launch_encode_mfma_dp<8, IdxT>(DP, vec, a, grid, st);
-    default: return false;
-    }
-}
-
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 // PQ encode of device-resident, already rotated rows.
@@ -177,7 +141,8 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     const bool mfma_possible = cb->T != 0 && cb->norms_ok && code_bytes == 1;
     bool use_mfma = mfma_possible;
     if (cb->variant == 1) use_mfma = false;
-    if (cb->variant == 2 && !mfma_possible) return PQHIP_EUNSUPPORTED;
+    if (cb->variant >= 2 && !mfma_possible) return PQHIP_EUNSUPPORTED;
+    const bool lds_argmin = cb->variant != 2;  // default: LDS-atomic argmin kernel
 
     if (use_mfma) {
         EncodeArgs a;
@@ -195,8 +160,9 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         const dim3 grid((unsigned)(wgs_per_xcd * 8));
         const bool vec = (cb->dsub % 4 == 0) && (cb->DP == cb->dsub) && (x_rs % 4 == 0) &&
                          ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
-        if (!launch_encode_mfma<uint8_t>(cb->T, cb->DP, vec, a, grid, st)) return PQHIP_EUNSUPPORTED;
-        cb->last_kernel = vec ? "k_encode_mfma<vec4>" : "k_encode_mfma<scalar-load>";
+        if (!launch_encode_mfma(lds_argmin ? 1 : 0, cb->T, cb->DP, vec, a, grid, st)) return PQHIP_EUNSUPPORTED;
+        cb->last_kernel = lds_argmin ? (vec ? "k_encode_mfma_lds<vec4>" : "k_encode_mfma_lds<scalar-load>")
+                                     : (vec ? "k_encode_mfma<vec4>" : "k_encode_mfma<scalar-load>");
     } else {
         const int64_t total = n * cb->M;
         const int block = 256;
@@ -542,7 +508,7 @@ int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && c
 
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {
-    if (!cb || variant < 0 || variant > 2) return PQHIP_EINVAL;
+    if (!cb || variant < 0 || variant > 3) return PQHIP_EINVAL;
     cb->variant = variant;
     return PQHIP_OK;
 }
