@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
                                                      int64_t c_rs, float* __restrict__ out,
                                                      int64_t o_rs, const float* __restrict__ cb,
                                                      int M, int K, int dsub, int rows_per_block,
-                                                     int* __restrict__ err)
+                                                     unsigned inv_cpr, int* __restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* tbl = reinterpret_cast<int*>(smem);  // [cpr]: m | (e << 16)
@@ -131,13 +131,16 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
     }
     __syncthreads();
 
-    const int q = blockDim.x / cpr, r = blockDim.x % cpr;  // per-iteration advance of (row, c)
     bool bad = false;
     for (int64_t row0 = (int64_t)blockIdx.x * rows_per_block; row0 < n;
          row0 += (int64_t)gridDim.x * rows_per_block) {
         const int rows = (n - row0 < rows_per_block) ? (int)(n - row0) : rows_per_block;
-        int row = threadIdx.x / cpr, c = threadIdx.x % cpr;
-        while (row < rows) {
+        const int nchunks = rows * cpr;  // < 2^16 (host guarantees), so L / cpr == (L * inv) >> 16
+        // independent iterations: unrolled so that 4 code loads, then 4 gathers, are in flight
+#pragma unroll 4
+        for (int L = threadIdx.x; L < nchunks; L += 256) {
+            const int row = (int)(((unsigned)L * inv_cpr) >> 16);
+            const int c = L - row * cpr;
             const int me = tbl[c];
             const int m = me & 0xffff, e = me >> 16;
             const int64_t grow = row0 + row;
@@ -146,14 +149,13 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
             const float* src = cb + ((int64_t)m * K + (int64_t)code) * dsub + e;
             float* dst = out + grow * o_rs + (int64_t)c * VEC;
             if (VEC == 4) {
-                *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
+                // streaming store: keep the L2 for the codebook, not for the 1.2 KB/row output
+                __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(src),
+                                            reinterpret_cast<f32x4*>(dst));
             } else {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) dst[v] = src[v];
             }
-            row += q;
-            c += r;
-            if (c >= cpr) { c -= cpr; row += 1; }
         }
     }
     if (bad) atomicOr(err, 1);

@@ -220,14 +220,24 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     const bool vec = (cb->dsub % 4 == 0) && (o_rs % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
     const int cpr = vec ? d / 4 : d;
-    const int rows_per_block = 64;
+    // rows per block: as many as keep rows*cpr < 2^16 and the magic division exact (<= 64)
+    int rows_per_block = 64;
+    unsigned inv_cpr = 0;
+    for (;; rows_per_block /= 2) {
+        inv_cpr = (unsigned)((65536 + cpr - 1) / cpr);
+        bool exact = (int64_t)rows_per_block * cpr < 65536;
+        for (int L = 0; exact && L < rows_per_block * cpr; ++L)
+            exact = (int)(((unsigned)L * inv_cpr) >> 16) == L / cpr;
+        if (exact || rows_per_block == 1) break;
+    }
+    if ((int64_t)cpr >= 65536) return PQHIP_EUNSUPPORTED;
     const unsigned grid =
         (unsigned)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, 256 * 8);
     const size_t lds = (size_t)cpr * sizeof(int);
 #define LAUNCH_REC(IDX, V)                                                                        \
     hipLaunchKernelGGL((k_reconstruct<IDX, V>), dim3(grid), dim3(256), lds, st,                   \
                        (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K,  \
-                       (int)cb->dsub, rows_per_block, cd.err)
+                       (int)cb->dsub, rows_per_block, inv_cpr, cd.err)
     if (code_bytes == 1) { if (vec) LAUNCH_REC(uint8_t, 4); else LAUNCH_REC(uint8_t, 1); }
     else if (code_bytes == 4) { if (vec) LAUNCH_REC(uint32_t, 4); else LAUNCH_REC(uint32_t, 1); }
     else return PQHIP_EUNSUPPORTED;
