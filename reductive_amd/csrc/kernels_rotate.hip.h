@@ -64,6 +64,162 @@ __global__ __launch_bounds__(256, 2) void k_rotate_mfma(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2/K4 v2  rotation GEMM with LDS-staged P slabs.
+//   out[n][c] = sum_k x[n][k] * Pm[k][c], rule-2 chains (restart every 256 k, blocks summed).
+// Workgroup = 4 waves = 64 rows x (2 * CT * 32) columns; wave (rg, ch) owns 32 rows x CT column
+// tiles.  x is the A operand and comes straight from global memory (each lane streams its own
+// row, 16 floats per slab, exactly like the encode kernel's B operand); the P slab [16 k][NC cols]
+// is staged through registers into a double-buffered LDS image shared by the four waves and read
+// back conflict-free (consecutive lanes = consecutive columns).  VALU work is ~8 selects per
+// 8*CT MFMAs, so the FP32 pipe is spent almost entirely on the matrix instruction.
+// SPLIT = d > 256: a second accumulator set holds the current k-block (rule 2).
+// VEC   = 16-byte aligned rows and d % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int CT, bool SPLIT, bool VEC>
+__global__ __launch_bounds__(256, 2) void k_rotate_gemm(const float* __restrict__ x, int64_t n,
+                                                        int64_t x_rs, const float* __restrict__ Pm,
+                                                        int d, float* __restrict__ out, int64_t o_rs)
+{
+    constexpr int KB = 16;            // k per slab (8 k-steps); 256 / KB slabs per rule-2 block
+    constexpr int NC = 2 * CT * 32;   // columns per workgroup
+    constexpr int NV = KB * NC / 4 / 256;  // float4 staged per thread per slab
+    static_assert(KB * NC / 4 % 256 == 0, "slab must divide over the workgroup");
+    __shared__ __attribute__((aligned(16))) float ps[2][KB][NC];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int rg = wave >> 1, ch = wave & 1;
+    const int64_t row0 = (int64_t)blockIdx.x * 64 + rg * 32;
+    const int col0 = blockIdx.y * NC;
+    const int cbase = ch * CT * 32 + j;  // column (inside the slab) of this lane's tile 0
+
+    int64_t arow = row0 + j;
+    if (arow >= n) arow = n - 1;
+    const float* xr = x + arow * x_rs;
+
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                         0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 tot[CT], cur[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { tot[ct] = zero; cur[ct] = zero; }
+
+    const int nslabs = (d + KB - 1) / KB;
+
+    // -- staging helpers: P slab -> registers -> LDS; x slab -> registers
+    f32x4 pst[NV];
+    auto load_p = [&](int slab) {
+        const int kb = slab * KB;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            const int kk = idx / (NC / 4), c4 = idx % (NC / 4);
+            const int k = kb + kk, c = col0 + 4 * c4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < d) {
+                const float* p = Pm + (int64_t)k * d + c;
+                if (VEC) {
+                    if (c < d) v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < d) v[e] = p[e];
+                }
+            }
+            pst[i] = v;
+        }
+    };
+    auto store_p = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            const int kk = idx / (NC / 4), c4 = idx % (NC / 4);
+            *reinterpret_cast<f32x4*>(&ps[buf][kk][4 * c4]) = pst[i];
+        }
+    };
+    // each lane fetches only the k = 2s + h elements of its row that it feeds to the MFMA
+    auto load_x = [&](int slab, float (&xv)[KB / 2]) {
+        const int kb = slab * KB + h;
+#pragma unroll
+        for (int s = 0; s < KB / 2; ++s) xv[s] = (kb + 2 * s < d) ? xr[kb + 2 * s] : 0.f;
+    };
+
+    float xv[KB / 2], xn[KB / 2];
+    load_p(0);
+    load_x(0, xv);
+    store_p(0);
+    __syncthreads();
+
+    for (int slab = 0; slab < nslabs; ++slab) {
+        const int buf = slab & 1;
+        const bool more = slab + 1 < nslabs;
+        if (more) { load_p(slab + 1); load_x(slab + 1, xn); }
+
+        if (SPLIT && slab > 0 && (slab % (kKC / KB)) == 0) {
+            // rule 2: a k-block ended -> fold it (first block: plain copy) and restart the chains
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (slab == kKC / KB) tot[ct] = cur[ct];
+                else
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[ct][r] = fadd(tot[ct][r], cur[ct][r]);
+                cur[ct] = zero;
+            }
+        }
+        // B fragments are fetched one k-step ahead (two register sets), so a ds_read's latency
+        // sits behind the five MFMAs of the step before it instead of in front of its own
+        float bf[2][CT];
+        {
+            const float* prow = &ps[buf][h][cbase];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) bf[0][ct] = prow[ct * 32];
+        }
+#pragma unroll
+        for (int s = 0; s < KB / 2; ++s) {
+            const float av = xv[s];
+            if (s + 1 < KB / 2) {
+                const float* prow = &ps[buf][2 * (s + 1) + h][cbase];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) bf[(s + 1) & 1][ct] = prow[ct * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this step's MFMAs
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (SPLIT) cur[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[s & 1][ct], cur[ct], 0, 0, 0);
+                else tot[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[s & 1][ct], tot[ct], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_p(buf ^ 1);
+#pragma unroll
+            for (int e = 0; e < KB / 2; ++e) xv[e] = xn[e];
+        }
+        __syncthreads();
+    }
+    if (SPLIT) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            if (nslabs <= kKC / KB) tot[ct] = cur[ct];
+            else
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[ct][r] = fadd(tot[ct][r], cur[ct][r]);
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = col0 + cbase + ct * 32;
+        if (col < d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < n) __builtin_nontemporal_store(tot[ct][r], out + row * o_rs + col);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Device self-test of the MFMA == fmaf-chain property (pqhip_selftest_mfma_chain).
 // One wave per trial: random A[32][k], B[k][32]; compares the MFMA tile with a scalar chain.
 // ---------------------------------------------------------------------------------------------

@@ -188,8 +188,15 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
                    int64_t o_rs, hipStream_t st)
 {
     if (n == 0) return PQHIP_OK;
-    const dim3 grid((unsigned)((n + 127) / 128), (unsigned)((d + 63) / 64));
-    hipLaunchKernelGGL(k_rotate_mfma, grid, dim3(256), 0, st, d_x, n, x_rs, Pm, d, d_out, o_rs);
+    const bool vec = (d % 4 == 0) && (x_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
+    const bool split = d > kKC;
+    constexpr int CT = 5;                      // 320 columns per workgroup
+    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((d + 2 * CT * 32 - 1) / (2 * CT * 32)));
+#define LAUNCH_ROT(SP, VE) \
+    hipLaunchKernelGGL((k_rotate_gemm<CT, SP, VE>), grid, dim3(256), 0, st, d_x, n, x_rs, Pm, d, d_out, o_rs)
+    if (split) { if (vec) LAUNCH_ROT(true, true); else LAUNCH_ROT(true, false); }
+    else { if (vec) LAUNCH_ROT(false, true); else LAUNCH_ROT(false, false); }
+#undef LAUNCH_ROT
     HIPCHK(hipGetLastError());
     return PQHIP_OK;
 }
