@@ -25,6 +25,16 @@ D, M, K = 300, 15, 256            # BASELINE.json metric: d=300, M=15, K=256
 DSUB = D // M
 FLOP_PER_VEC = 2 * K * D          # distance GEMM only: 153,600
 BYTES_PER_VEC = 4 * D + M         # algorithmic HBM bytes per vector: 1,215
+
+
+def set_shape(d, m):
+    """non-headline shapes (e.g. BASELINE configs[4]: d=768, M=48) for exploration runs"""
+    global D, M, DSUB, FLOP_PER_VEC, BYTES_PER_VEC
+    D, M = d, m
+    DSUB = D // M
+    FLOP_PER_VEC = 2 * K * D
+    BYTES_PER_VEC = 4 * D + M
+
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
@@ -42,6 +52,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="encode")
+    ap.add_argument("--d", type=int, default=300)
+    ap.add_argument("--m", type=int, default=15)
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 anchor kernel, 2 MFMA kernel")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -70,6 +82,8 @@ def load_pmc_traffic(workload, rows):
 
 def main():
     args = parse()
+    if (args.d, args.m) != (300, 15):
+        set_shape(args.d, args.m)
     import torch
     import torch.distributed as dist
 
@@ -154,15 +168,17 @@ def main():
     if rank == 0:
         total_rows = world * rows
         value = total_rows * args.steps / elapsed
-        names = {"encode": "vectors/sec PQ encode (d=300, M=15, K=256)",
-                 "opq_encode": "vectors/sec OPQ rotate+encode (d=300, M=15, K=256)",
-                 "reconstruct": "vectors/sec PQ reconstruct (d=300, M=15, K=256)"}
+        shape = "(d=%d, M=%d, K=%d)" % (D, M, K)
+        names = {"encode": "vectors/sec PQ encode " + shape,
+                 "opq_encode": "vectors/sec OPQ rotate+encode " + shape,
+                 "reconstruct": "vectors/sec PQ reconstruct " + shape}
         rec = {
             "metric": names[args.workload], "value": value, "unit": "vectors/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload], "rows_per_gpu": rows,
+            "config": {"workload": WORKLOADS[args.workload] if (D, M) == (300, 15) else
+                       "%s, non-headline shape d=%d M=%d" % (args.workload, D, M), "rows_per_gpu": rows,
                        "rows_total": total_rows, "d": D, "M": M, "K": K, "shards": shards,
                        "placement": "inputs and outputs resident in HBM; C ABI device entry point"},
         }

@@ -1,0 +1,127 @@
+//! pqhip_ffi.rs -- the reference-side binding of libpqhip.so (include/pqhip.h).
+//!
+//! SOURCE ONLY: this image has no rustc/cargo, so this file is never compiled in this
+//! repository's pipeline; every call below is mirrored by the C++ (include/reductive_amd/pq.hpp)
+//! and Python (reductive_amd/pq.py) host layers, which ARE executed by the test-suite.
+//!
+//! Drop into `reductive/src/pq/` behind a cargo feature `hip`, add `mod pqhip_ffi;` to
+//! `src/pq/mod.rs`, and route the two hot-path methods of `impl QuantizeVector<A> for Pq<A>` /
+//! `impl Reconstruct<A> for Pq<A>` (src/pq/pq.rs:268-283, 309-327) through `try_quantize_batch`
+//! / `try_reconstruct_batch` (see INTEGRATION.md for the five-line patch of pq.rs).
+#![cfg(feature = "hip")]
+#![allow(non_camel_case_types)]
+
+use std::any::TypeId;
+use std::collections::HashMap;
+use std::os::raw::{c_char, c_void};
+use std::sync::{Mutex, Once};
+
+use ndarray::{ArrayBase, ArrayView2, ArrayView3, ArrayViewMut2, Data, Ix2};
+
+#[repr(C)]
+pub struct pqhip_ctx { _p: [u8; 0] }
+#[repr(C)]
+pub struct pqhip_codebook { _p: [u8; 0] }
+
+pub const PQHIP_OK: i32 = 0;
+pub const PQHIP_ECODE_RANGE: i32 = 3;
+pub const PQHIP_EINDEX_WIDTH: i32 = 4;
+
+#[link(name = "pqhip")]
+extern "C" {
+    pub fn pqhip_version() -> i32;
+    pub fn pqhip_strerror(status: i32) -> *const c_char;
+    pub fn pqhip_device_count(out_count: *mut i32) -> i32;
+    pub fn pqhip_ctx_create(devices: *const i32, n_devices: i32, out: *mut *mut pqhip_ctx) -> i32;
+    pub fn pqhip_ctx_destroy(ctx: *mut pqhip_ctx);
+    pub fn pqhip_codebook_create(ctx: *mut pqhip_ctx, quantizers: *const f32, n_subquantizers: i64,
+        n_centroids: i64, sub_dim: i64, projection: *const f32, out: *mut *mut pqhip_codebook) -> i32;
+    pub fn pqhip_codebook_destroy(cb: *mut pqhip_codebook);
+    pub fn pqhip_quantize_batch_f32(cb: *mut pqhip_codebook, x: *const f32, n_rows: i64,
+        x_row_stride: i64, x_col_stride: i64, codes: *mut c_void, code_bytes: i32,
+        codes_row_stride: i64, codes_col_stride: i64) -> i32;
+    pub fn pqhip_reconstruct_batch_f32(cb: *mut pqhip_codebook, codes: *const c_void, code_bytes: i32,
+        n_rows: i64, codes_row_stride: i64, codes_col_stride: i64, out: *mut f32,
+        out_row_stride: i64, out_col_stride: i64) -> i32;
+}
+
+/// Batches smaller than this stay on the CPU path (a launch + PCIe round trip is pointless).
+const MIN_GPU_ROWS: usize = 4096;
+
+struct Handles { ctx: *mut pqhip_ctx, books: HashMap<(usize, usize, usize), *mut pqhip_codebook> }
+unsafe impl Send for Handles {}
+static INIT: Once = Once::new();
+static mut HANDLES: Option<Mutex<Handles>> = None;
+
+fn handles() -> Option<&'static Mutex<Handles>> {
+    unsafe {
+        INIT.call_once(|| {
+            let mut ctx = std::ptr::null_mut();
+            if pqhip_ctx_create(std::ptr::null(), 0, &mut ctx) == PQHIP_OK {
+                HANDLES = Some(Mutex::new(Handles { ctx, books: HashMap::new() }));
+            }
+        });
+        HANDLES.as_ref()
+    }
+}
+
+/// Device image of a `Pq<f32>`, cached by the identity (data pointers + len) of its arrays so that
+/// `Pq` keeps `#[derive(Clone, Debug, PartialEq)]` and literal construction (pq.rs:28-32, opq.rs:95-98).
+fn codebook(q: ArrayView3<f32>, p: Option<ArrayView2<f32>>) -> Option<*mut pqhip_codebook> {
+    let q = q.as_standard_layout();
+    let p = p.map(|p| p.as_standard_layout().into_owned());
+    let key = (q.as_ptr() as usize, q.len(), p.as_ref().map_or(0, |p| p.as_ptr() as usize));
+    let mut h = handles()?.lock().ok()?;
+    if let Some(cb) = h.books.get(&key) { return Some(*cb); }
+    let (m, k, dsub) = q.dim();
+    let mut cb = std::ptr::null_mut();
+    let rc = unsafe { pqhip_codebook_create(h.ctx, q.as_ptr(), m as i64, k as i64, dsub as i64,
+        p.as_ref().map_or(std::ptr::null(), |p| p.as_ptr()), &mut cb) };
+    if rc != PQHIP_OK { return None; }
+    h.books.insert(key, cb);
+    Some(cb)
+}
+
+fn same<A: 'static, B: 'static>() -> bool { TypeId::of::<A>() == TypeId::of::<B>() }
+
+/// Returns true when the GPU produced the result; false => caller runs `primitives::*` unchanged.
+/// The shape asserts of primitives.rs:74-87 are performed by the caller BEFORE this call, so panic
+/// messages are unchanged.
+pub fn try_quantize_batch<A, I, S>(quantizers: ArrayView3<A>, projection: Option<ArrayView2<A>>,
+    x: &ArrayBase<S, Ix2>, mut quantized: ArrayViewMut2<I>) -> bool
+where A: 'static + Copy, I: 'static + Copy, S: Data<Elem = A>,
+{
+    if !same::<A, f32>() || x.nrows() < MIN_GPU_ROWS { return false; }
+    let code_bytes = std::mem::size_of::<I>() as i32;
+    if !(same::<I, u8>() || same::<I, u16>() || same::<I, u32>() || same::<I, u64>() || same::<I, usize>()) { return false; }
+    // SAFETY: A == f32 was checked above.
+    let (q, p, x): (ArrayView3<f32>, Option<ArrayView2<f32>>, ArrayView2<f32>) = unsafe {
+        (std::mem::transmute(quantizers), std::mem::transmute(projection), std::mem::transmute(x.view()))
+    };
+    let cb = match codebook(q, p) { Some(cb) => cb, None => return false };
+    let (xs, qs) = (x.strides(), quantized.strides());
+    if xs.iter().chain(qs.iter()).any(|&s| s < 0) { return false; }
+    let rc = unsafe { pqhip_quantize_batch_f32(cb, x.as_ptr(), x.nrows() as i64, xs[0] as i64, xs[1] as i64,
+        quantized.as_mut_ptr() as *mut c_void, code_bytes, qs[0] as i64, qs[1] as i64) };
+    // EINDEX_WIDTH: K-1 > I::MAX. The reference's batch path wraps silently (primitives.rs:98-100);
+    // fall back so that (odd) behaviour is preserved bit for bit.
+    rc == PQHIP_OK
+}
+
+pub fn try_reconstruct_batch<A, I, S>(quantizers: ArrayView3<A>, projection: Option<ArrayView2<A>>,
+    quantized: &ArrayBase<S, Ix2>, mut reconstructions: ArrayViewMut2<A>) -> bool
+where A: 'static + Copy, I: 'static + Copy, S: Data<Elem = I>,
+{
+    if !same::<A, f32>() || quantized.nrows() < MIN_GPU_ROWS { return false; }
+    if !(same::<I, u8>() || same::<I, u16>() || same::<I, u32>() || same::<I, u64>() || same::<I, usize>()) { return false; }
+    let (q, p): (ArrayView3<f32>, Option<ArrayView2<f32>>) =
+        unsafe { (std::mem::transmute(quantizers), std::mem::transmute(projection)) };
+    let cb = match codebook(q, p) { Some(cb) => cb, None => return false };
+    let (cs, os) = (quantized.strides(), reconstructions.strides());
+    if cs.iter().chain(os.iter()).any(|&s| s < 0) { return false; }
+    let rc = unsafe { pqhip_reconstruct_batch_f32(cb, quantized.as_ptr() as *const c_void,
+        std::mem::size_of::<I>() as i32, quantized.nrows() as i64, cs[0] as i64, cs[1] as i64,
+        reconstructions.as_mut_ptr() as *mut f32, os[0] as i64, os[1] as i64) };
+    if rc == PQHIP_ECODE_RANGE { panic!("ndarray: index out of bounds"); }   // primitives.rs:146
+    rc == PQHIP_OK
+}
