@@ -117,7 +117,9 @@ int32_t pqhip_check_codes_dev(pqhip_codebook *cb, int32_t device_slot, void *str
 
 /* ---- knobs used by the test-suite and the bench (not part of the reference surface) -------- */
 /* force a kernel variant for encode: 0 = auto, 1 = scalar VALU anchor kernel,
- * 2 = MFMA kernel with VALU argmin, 3 = MFMA kernel with LDS-atomic argmin (the auto choice)  */
+ * 2 = MFMA kernel with VALU argmin, 3 = MFMA + LDS-atomic argmin with register-resident codebook
+ * fragments (2 waves/SIMD), 4 = MFMA + LDS-atomic argmin with LDS-resident fragments (3 waves/SIMD;
+ * the auto choice) */
 int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);
 /* name of the encode kernel the last device call on this codebook launched ("" if none)        */
 const char *pqhip_last_encode_kernel(const pqhip_codebook *cb);

@@ -6,7 +6,8 @@
 #include "kernels_mfma.hip.h"
 
 namespace pqhip {
-// KIND 0: k_encode_mfma (VALU argmin epilogue); KIND 1: k_encode_mfma_lds (LDS-atomic argmin).
+// KIND 0: k_encode_mfma (VALU argmin epilogue); KIND 1: k_encode_mfma_lds (LDS-atomic argmin,
+// resident A fragments, 2 waves/SIMD); KIND 2: k_encode_mfma_lds3 (A fragments in LDS, 3 waves/SIMD).
 // Returns false when (T, DP) has no instantiation.  u8 codes.
 template <int KIND, int T>
 bool launch_encode_mfma_t(int DP, bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st);
@@ -15,6 +16,7 @@ bool launch_encode_mfma_t(int DP, bool vec, const EncodeArgs& a, dim3 grid, hipS
     extern template bool launch_encode_mfma_t<KIND, T>(int, bool, const EncodeArgs&, dim3, hipStream_t);
 PQHIP_DECL_LAUNCH(0, 1) PQHIP_DECL_LAUNCH(0, 2) PQHIP_DECL_LAUNCH(0, 4) PQHIP_DECL_LAUNCH(0, 8)
 PQHIP_DECL_LAUNCH(1, 1) PQHIP_DECL_LAUNCH(1, 2) PQHIP_DECL_LAUNCH(1, 4) PQHIP_DECL_LAUNCH(1, 8)
+PQHIP_DECL_LAUNCH(2, 1) PQHIP_DECL_LAUNCH(2, 2) PQHIP_DECL_LAUNCH(2, 4) PQHIP_DECL_LAUNCH(2, 8)
 #undef PQHIP_DECL_LAUNCH
 
 inline bool launch_encode_mfma(int kind, int T, int DP, bool vec, const EncodeArgs& a, dim3 grid,
@@ -24,6 +26,7 @@ inline bool launch_encode_mfma(int kind, int T, int DP, bool vec, const EncodeAr
     if (kind == KIND && T == TT) return launch_encode_mfma_t<KIND, TT>(DP, vec, a, grid, st);
     PQHIP_CASE(0, 1) PQHIP_CASE(0, 2) PQHIP_CASE(0, 4) PQHIP_CASE(0, 8)
     PQHIP_CASE(1, 1) PQHIP_CASE(1, 2) PQHIP_CASE(1, 4) PQHIP_CASE(1, 8)
+    PQHIP_CASE(2, 1) PQHIP_CASE(2, 2) PQHIP_CASE(2, 4) PQHIP_CASE(2, 8)
 #undef PQHIP_CASE
     return false;
 }

@@ -1,5 +1,6 @@
 // encode_launch.hip -- compiled once per (PQ_KIND, PQ_T) by the Makefile.
 #include "encode_launch.h"
+#include <cstdlib>
 #include "kernels_mfma_lds.hip.h"
 
 #ifndef PQ_KIND
@@ -8,15 +9,26 @@
 
 namespace pqhip {
 
+// PQHIP_DEBUG_LDS_PAD=<bytes>: extra dynamic LDS per workgroup (occupancy experiments only)
+static unsigned debug_lds_pad()
+{
+    static const unsigned v = [] { const char* e = getenv("PQHIP_DEBUG_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    return v;
+}
+
 template <int KIND, int T, int DP>
 static void launch_vec(bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
 {
+    const unsigned pad = debug_lds_pad();
     if (KIND == 0) {
-        if (vec) hipLaunchKernelGGL((k_encode_mfma<T, DP, true, uint8_t>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_encode_mfma<T, DP, false, uint8_t>), grid, dim3(256), 0, st, a);
+        if (vec) hipLaunchKernelGGL((k_encode_mfma<T, DP, true, uint8_t>), grid, dim3(256), pad, st, a);
+        else hipLaunchKernelGGL((k_encode_mfma<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
+    } else if (KIND == 1) {
+        if (vec) hipLaunchKernelGGL((k_encode_mfma_lds<T, DP, true, uint8_t>), grid, dim3(256), pad, st, a);
+        else hipLaunchKernelGGL((k_encode_mfma_lds<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
     } else {
-        if (vec) hipLaunchKernelGGL((k_encode_mfma_lds<T, DP, true, uint8_t>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_encode_mfma_lds<T, DP, false, uint8_t>), grid, dim3(256), 0, st, a);
+        if (vec) hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, true, uint8_t>), grid, dim3(256), pad, st, a);
+        else hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
     }
 }
 

@@ -215,4 +215,183 @@ __global__ __launch_bounds__(256, 2) void k_encode_mfma_lds(EncodeArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1, third generation: as k_encode_mfma_lds, but the sub-codebook's MFMA fragments live in a
+// per-workgroup LDS image instead of 80 resident VGPRs, so THREE waves fit on a SIMD (<= 168
+// VGPRs).  All four waves of a workgroup work on the same subquantizer m (different 32-row
+// streams); A fragments of the next chain are read from LDS while the VALU forms the current
+// tile's keys; ||c||^2 of the next tile is read behind the atomics, during the chain.
+// Occupancy experiment on MI355X (same kernel body, 1 vs 2 waves/SIMD): 51.8 % -> 66.4 % of MFMA
+// peak -- the loop is latency-bound per wave, so the third wave is worth more than the registers.
+// ---------------------------------------------------------------------------------------------
+template <int T, int DP, bool VEC, typename IdxT>
+__global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
+{
+    constexpr int S = DP / 2;
+    __shared__ __attribute__((aligned(16))) float afrag_s[T][S][64];
+    __shared__ __attribute__((aligned(16))) long long slot_s[4][T][64];
+    __shared__ __attribute__((aligned(16))) float cc_s[T * 32];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+
+    // ---- workgroup -> (row group, m); XCD-aware: the M workgroups of one row group share an XCD
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t q = b >> 3;
+    const int64_t g_local = q / a.M;
+    const int m = (int)(q - g_local * a.M);
+    const int64_t group = g_local * 8 + xcd;                  // group of 4 * rows_per_item rows
+    const bool wg_active = (g_local < a.chunks_per_xcd) && (group < a.n_chunks);
+
+    constexpr long long kKeyInit = 0x7fffffffffffffffll;
+    if (wg_active) {
+        const float* fp = a.frags + (int64_t)m * T * S * 64;
+        float* dst = &afrag_s[0][0][0];
+        for (int i = threadIdx.x; i < T * S * 64; i += 256) dst[i] = fp[i];
+        const float* ccm = a.cc + (int64_t)m * T * 32;
+        for (int i = threadIdx.x; i < T * 32; i += 256) cc_s[i] = ccm[i];
+#pragma unroll
+        for (int t = 0; t < T; ++t) slot_s[wave][t][lane] = kKeyInit;
+    }
+    __syncthreads();
+    const int64_t row_begin = (group * 4 + wave) * a.rows_per_item;
+    if (!wg_active || row_begin >= a.n) return;
+    int64_t row_end = row_begin + a.rows_per_item;
+    if (row_end > a.n) row_end = a.n;
+    const float* xcol = a.x + (int64_t)m * a.dsub;
+    const int dsub = a.dsub;
+
+    auto load_tile = [&](float (&v)[DP], int64_t tile_row0) {
+        int64_t row = tile_row0 + j;
+        if (row >= a.n) row = a.n - 1;
+        const float* p = xcol + row * a.x_rs;
+        if (VEC) {
+#pragma unroll
+            for (int e = 0; e < DP; e += 4) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(p + e);
+                v[e] = qv[0]; v[e + 1] = qv[1]; v[e + 2] = qv[2]; v[e + 3] = qv[3];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < DP; ++e) v[e] = (e < dsub) ? p[e] : 0.f;
+        }
+    };
+    auto prep_tile = [&](const float (&v)[DP], float (&bop)[S], float& xx) {
+        xx = norm_unrolled_padded<DP>(v, dsub);
+#pragma unroll
+        for (int s = 0; s < S; ++s) bop[s] = h ? v[2 * s + 1] : v[2 * s];
+    };
+    auto read_cc = [&](int t, f32x4 (&c)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            c[g] = *reinterpret_cast<const f32x4*>(&cc_s[32 * t + 8 * g + 4 * h]);
+    };
+
+    int lo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        lo[r] = (r & 3) + 8 * (r >> 2);
+        asm volatile("" : "+v"(lo[r]));
+    }
+
+    const int64_t last_tile0 = row_begin + ((row_end - row_begin - 1) / 32) * 32;
+    float vn[DP];
+    float bop[S];
+    float xx;
+    load_tile(vn, row_begin);
+    prep_tile(vn, bop, xx);
+    load_tile(vn, (row_begin + 32 <= last_tile0) ? row_begin + 32 : last_tile0);
+
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag_s[0][s][lane], bop[s], acc, 0, 0, 0);
+    f32x4 c4[4];
+    read_cc(0, c4);
+
+    for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
+        float bop_n[S];
+        float xx_n;
+        prep_tile(vn, bop_n, xx_n);
+        load_tile(vn, (row0 + 64 <= last_tile0) ? row0 + 64 : last_tile0);
+        const f32x2 xx2 = {xx, xx};
+
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            // LDS queue is drained here for free: the previous chain took >= 640 cycles
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+            float an[S];  // A fragments of the NEXT chain: in flight while the VALU works below
+#pragma unroll
+            for (int s = 0; s < S; ++s) an[s] = afrag_s[(t + 1) % T][s][lane];
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- VALU: 16 distances -> 16 keys ----
+            long long key[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x2 c01 = {c4[g][0], c4[g][1]}, c23 = {c4[g][2], c4[g][3]};
+                f32x2 t01, t23;
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t01) : "v"(xx2), "v"(c01));
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t23) : "v"(xx2), "v"(c23));
+                const float tt[4] = {t01[0], t01[1], t23[0], t23[1]};
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int r = 4 * g + qq;
+                    const float d = ffma(acc[r], -2.0f, tt[qq]);
+                    key[r] = ((long long)__float_as_int(d) << 32) | (long long)(unsigned)lo[r];
+                }
+                asm volatile("" ::"v"(t01), "v"(t23));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- next chain + this tile's atomics + next tile's norms (queued behind the atomics) ----
+            f32x16 nacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                           0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            long long* slot = &slot_s[wave][t][lane];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(an[s], (t + 1 < T) ? bop[s] : bop_n[s],
+                                                           nacc, 0, 0, 0);
+#pragma unroll
+                for (int r = (16 * s) / S; r < (16 * (s + 1)) / S; ++r)
+                    (void)__hip_atomic_fetch_min(slot, key[r], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            read_cc((t + 1) % T, c4);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = nacc;
+        }
+
+        float best = __builtin_inff();
+        int bidx = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const long long k = slot_s[wave][t][lane];
+            slot_s[wave][t][lane] = kKeyInit;
+            const float d = __int_as_float((int)(k >> 32));
+            const bool lt = d < best;
+            best = lt ? d : best;
+            bidx = lt ? ((int)(unsigned)k + 32 * t) : bidx;
+        }
+        const bool neg = best < 0.f;
+        bidx += 4 * h;
+        const float od = __shfl_xor(best, 32);
+        const int oi = __shfl_xor(bidx, 32);
+        if (od < best || (od == best && oi < bidx)) bidx = oi;
+
+        const int64_t row = row0 + j;
+        const bool valid = row < a.n;
+        if (__builtin_amdgcn_ballot_w64(!(xx < kBigNorm) || neg) != 0ull) {
+            encode_tile_slow<IdxT>(a, m, row, valid);
+        } else if (h == 0 && valid) {
+            reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) bop[s] = bop_n[s];
+        xx = xx_n;
+    }
+}
+
 }  // namespace pqhip

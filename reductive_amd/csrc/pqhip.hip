@@ -142,27 +142,41 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     bool use_mfma = mfma_possible;
     if (cb->variant == 1) use_mfma = false;
     if (cb->variant >= 2 && !mfma_possible) return PQHIP_EUNSUPPORTED;
-    const bool lds_argmin = cb->variant != 2;  // default: LDS-atomic argmin kernel
 
     if (use_mfma) {
         EncodeArgs a;
         a.x = d_x; a.n = n; a.x_rs = x_rs; a.out = d_codes; a.o_rs = o_rs;
         a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
         a.M = (int)cb->M; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
-        // ~2 items per wave slot (256 CUs x 8 waves), 32..1024 rows each
-        int64_t rpi = round_up((n * cb->M + 4095) / 4096, 32);
-        rpi = std::max<int64_t>(32, std::min<int64_t>(1024, rpi));
-        a.rows_per_item = (int)rpi;
-        a.n_chunks = (n + rpi - 1) / rpi;
-        a.chunks_per_xcd = (a.n_chunks + 7) / 8;
-        const int64_t items_per_xcd = a.chunks_per_xcd * cb->M;
-        const int64_t wgs_per_xcd = (items_per_xcd + 3) / 4;
-        const dim3 grid((unsigned)(wgs_per_xcd * 8));
+        // kernel kind: 0 VALU argmin, 1 LDS argmin (2 waves/SIMD), 2 LDS argmin + LDS A fragments
+        const int kind = cb->variant == 2 ? 0 : cb->variant == 3 ? 1 : 2;
+        dim3 grid;
+        if (kind == 2) {
+            // one workgroup = one subquantizer x 4 row streams (one per wave)
+            int64_t rpi = round_up((n * cb->M + 4 * 4096 - 1) / (4 * 4096), 32);
+            rpi = std::max<int64_t>(32, std::min<int64_t>(1024, rpi));
+            a.rows_per_item = (int)rpi;
+            a.n_chunks = (n + 4 * rpi - 1) / (4 * rpi);       // row groups
+            a.chunks_per_xcd = (a.n_chunks + 7) / 8;
+            grid = dim3((unsigned)(a.chunks_per_xcd * cb->M * 8));
+        } else {
+            // ~2 items per wave slot (256 CUs x 8 waves), 32..1024 rows each
+            int64_t rpi = round_up((n * cb->M + 4095) / 4096, 32);
+            rpi = std::max<int64_t>(32, std::min<int64_t>(1024, rpi));
+            a.rows_per_item = (int)rpi;
+            a.n_chunks = (n + rpi - 1) / rpi;
+            a.chunks_per_xcd = (a.n_chunks + 7) / 8;
+            const int64_t items_per_xcd = a.chunks_per_xcd * cb->M;
+            const int64_t wgs_per_xcd = (items_per_xcd + 3) / 4;
+            grid = dim3((unsigned)(wgs_per_xcd * 8));
+        }
         const bool vec = (cb->dsub % 4 == 0) && (cb->DP == cb->dsub) && (x_rs % 4 == 0) &&
                          ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
-        if (!launch_encode_mfma(lds_argmin ? 1 : 0, cb->T, cb->DP, vec, a, grid, st)) return PQHIP_EUNSUPPORTED;
-        cb->last_kernel = lds_argmin ? (vec ? "k_encode_mfma_lds<vec4>" : "k_encode_mfma_lds<scalar-load>")
-                                     : (vec ? "k_encode_mfma<vec4>" : "k_encode_mfma<scalar-load>");
+        if (!launch_encode_mfma(kind, cb->T, cb->DP, vec, a, grid, st)) return PQHIP_EUNSUPPORTED;
+        static const char* const names[3][2] = {{"k_encode_mfma<scalar-load>", "k_encode_mfma<vec4>"},
+                                                {"k_encode_mfma_lds<scalar-load>", "k_encode_mfma_lds<vec4>"},
+                                                {"k_encode_mfma_lds3<scalar-load>", "k_encode_mfma_lds3<vec4>"}};
+        cb->last_kernel = names[kind][vec ? 1 : 0];
     } else {
         const int64_t total = n * cb->M;
         const int block = 256;
@@ -525,7 +539,7 @@ int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && c
 
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {
-    if (!cb || variant < 0 || variant > 3) return PQHIP_EINVAL;
+    if (!cb || variant < 0 || variant > 4) return PQHIP_EINVAL;
     cb->variant = variant;
     return PQHIP_OK;
 }

@@ -110,13 +110,13 @@ SHAPES = [  # n, M, K, dsub
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_encode_matches_oracle(ra, shape, variant):
     n, M, K, dsub = shape
     q = synth.normalish(100 + n, (M, K, dsub))
     x = synth.normalish(200 + n, (n, M * dsub))
     dt = np.uint8 if K <= 256 else np.uint16
-    if variant == 2 and (K > 256 or dsub > 32):
+    if variant >= 2 and (K > 256 or dsub > 32):
         pytest.skip("shape not covered by the MFMA kernels (anchor kernel is used)")
     want = orc.quantize_batch(q, x, dtype=dt)
     pq = _pq(ra, q, variant=variant)
@@ -139,7 +139,7 @@ def test_encode_special_values(ra):
     x[151] *= np.float32(3e19)          # xx overflows to inf
     x[160] *= np.float32(1e-30)         # subnormal products
     want = orc.quantize_batch(q, x)
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         got = _pq(ra, q, variant=variant).quantize_batch(x)
         assert got.tobytes() == want.tobytes(), variant
     # NaN / Inf / huge centroids: codebook leaves the fast path entirely
@@ -166,7 +166,7 @@ def test_encode_exact_and_near_ties(ra):
     x[192:256, :dsub] = big
     want = orc.quantize_batch(q, x)
     assert (want[:64, 0] == 7).all() and (want[64:128, 1] == 0).all()
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         assert _pq(ra, q, variant=variant).quantize_batch(x).tobytes() == want.tobytes()
 
 
@@ -277,7 +277,7 @@ def test_device_resident_and_properties_at_scale(ra):
     x = torch.randn((n, M * dsub), device="cuda", dtype=torch.float32, generator=g)
     codes = pq.quantize_batch_device(x)
     torch.cuda.synchronize()
-    assert pq.last_encode_kernel() == "k_encode_mfma_lds<vec4>"
+    assert pq.last_encode_kernel() == "k_encode_mfma_lds3<vec4>"
     # (1) sampled rows against the oracle: first / last 32k rows + a strided sample
     idx = torch.cat([torch.arange(0, 32768), torch.arange(n - 32768, n),
                      torch.arange(0, n, 97)]).cuda()
