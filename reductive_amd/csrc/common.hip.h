@@ -85,6 +85,51 @@ __device__ __forceinline__ float norm_unrolled_padded(const float (&v)[DP], int 
     return s;
 }
 
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
+{
+    f32x2 r;  // two independent IEEE binary32 adds
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b)
+{
+    f32x2 r;  // two independent IEEE binary32 multiplies
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// rule 1 (ndarray unrolled_dot(x, x)) for a register vector of compile-time length D held as D/2
+// pairs, with packed arithmetic: identical roundings, about half the instructions of the scalar form.
+template <int D>
+__device__ __forceinline__ float norm_unrolled_packed(const f32x2 (&v2)[D / 2])
+{
+    static_assert(D % 2 == 0, "pairs");
+    constexpr int C = D / 8;          // full chunks of 8
+    constexpr int NF = C * 8;
+    f32x2 sq[D / 2];
+#pragma unroll
+    for (int i = 0; i < D / 2; ++i) sq[i] = pk_mul(v2[i], v2[i]);
+    float s = 0.f;
+    if (C > 0) {
+        f32x2 pp[4];  // pp[l2] = (p[2 l2], p[2 l2 + 1]);  p[l] = 0 + sq[l] (+ sq[8 + l] ...)
+#pragma unroll
+        for (int l2 = 0; l2 < 4; ++l2) {
+            pp[l2] = sq[l2];  // 0 + x == x exactly for x >= +0 or NaN
+#pragma unroll
+            for (int c = 1; c < C; ++c) pp[l2] = pk_add(pp[l2], sq[4 * c + l2]);
+        }
+        const f32x2 a = pk_add(pp[0], pp[2]);  // (p0 + p4, p1 + p5)
+        const f32x2 b = pk_add(pp[1], pp[3]);  // (p2 + p6, p3 + p7)
+        s = fadd(fadd(fadd(a[0], a[1]), b[0]), b[1]);  // 0 + (p0 + p4) is exact
+    }
+#pragma unroll
+    for (int e = NF; e < D; ++e) s = fadd(s, sq[e / 2][e & 1]);
+    return s;
+}
+
 // One sequential fmaf chain with restarts every kKC (rule 2), global operands with strides.
 __device__ inline float chain_dot_global(const float* __restrict__ a, int64_t as,
                                          const float* __restrict__ b, int64_t bs, int n)

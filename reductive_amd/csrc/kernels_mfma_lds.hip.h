@@ -20,8 +20,6 @@
 
 namespace pqhip {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 template <int T, int DP, bool VEC, typename IdxT>
 __global__ __launch_bounds__(256, 2) void k_encode_mfma_lds(EncodeArgs a)
 {
@@ -264,25 +262,36 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
     const float* xcol = a.x + (int64_t)m * a.dsub;
     const int dsub = a.dsub;
 
-    auto load_tile = [&](float (&v)[DP], int64_t tile_row0) {
-        int64_t row = tile_row0 + j;
-        if (row >= a.n) row = a.n - 1;
-        const float* p = xcol + row * a.x_rs;
+    // x tile: lane j reads the DP floats of its row's sub-vector.  Rows past the end are clamped
+    // to the last row (their result is never stored).
+    const float* const plast = xcol + (a.n - 1) * a.x_rs;
+    auto load_tile = [&](f32x2 (&v2)[DP / 2], int64_t tile_row0) {
+        const int left = (int)((a.n - tile_row0 < 32) ? a.n - tile_row0 : 32);  // wave-uniform
+        const float* p = (j < left) ? xcol + (tile_row0 + j) * a.x_rs : plast;
         if (VEC) {
 #pragma unroll
             for (int e = 0; e < DP; e += 4) {
                 const f32x4 qv = *reinterpret_cast<const f32x4*>(p + e);
-                v[e] = qv[0]; v[e + 1] = qv[1]; v[e + 2] = qv[2]; v[e + 3] = qv[3];
+                v2[e / 2] = (f32x2){qv[0], qv[1]};
+                v2[e / 2 + 1] = (f32x2){qv[2], qv[3]};
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < DP; ++e) v[e] = (e < dsub) ? p[e] : 0.f;
+            for (int e = 0; e < DP; e += 2)
+                v2[e / 2] = (f32x2){(e < dsub) ? p[e] : 0.f, (e + 1 < dsub) ? p[e + 1] : 0.f};
         }
     };
-    auto prep_tile = [&](const float (&v)[DP], float (&bop)[S], float& xx) {
-        xx = norm_unrolled_padded<DP>(v, dsub);
+    auto prep_tile = [&](const f32x2 (&v2)[DP / 2], float (&bop)[S], float& xx) {
+        if (dsub == DP) {
+            xx = norm_unrolled_packed<DP>(v2);
+        } else {
+            float v[DP];
 #pragma unroll
-        for (int s = 0; s < S; ++s) bop[s] = h ? v[2 * s + 1] : v[2 * s];
+            for (int e = 0; e < DP; ++e) v[e] = v2[e / 2][e & 1];
+            xx = norm_unrolled_padded<DP>(v, dsub);
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) bop[s] = h ? v2[s][1] : v2[s][0];
     };
     auto read_cc = [&](int t, f32x4 (&c)[4]) {
 #pragma unroll
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
     }
 
     const int64_t last_tile0 = row_begin + ((row_end - row_begin - 1) / 32) * 32;
-    float vn[DP];
+    f32x2 vn[DP / 2];
     float bop[S];
     float xx;
     load_tile(vn, row_begin);
@@ -314,9 +323,7 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
 
     for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
         float bop_n[S];
-        float xx_n;
-        prep_tile(vn, bop_n, xx_n);
-        load_tile(vn, (row0 + 64 <= last_tile0) ? row0 + 64 : last_tile0);
+        float xx_n = 0.f;
         const f32x2 xx2 = {xx, xx};
 
 #pragma unroll
@@ -324,6 +331,13 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
             // LDS queue is drained here for free: the previous chain took >= 640 cycles
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             __builtin_amdgcn_sched_barrier(0);
+            if (t == T - 1) {
+                // operands of the next x tile are formed only now, when `bop` is dead (its last
+                // chain was issued one step ago): no register copies at the loop seam; the tile
+                // after next starts its trip from HBM right away
+                prep_tile(vn, bop_n, xx_n);
+                load_tile(vn, (row0 + 64 <= last_tile0) ? row0 + 64 : last_tile0);
+            }
             float an[S];  // A fragments of the NEXT chain: in flight while the VALU works below
 #pragma unroll
             for (int s = 0; s < S; ++s) an[s] = afrag_s[(t + 1) % T][s][lane];
