@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_rotate_mfma(const float* __restrict_
 // is staged through registers into a double-buffered LDS image shared by the four waves and read
 // back conflict-free (consecutive lanes = consecutive columns).  VALU work is ~8 selects per
 // 8*CT MFMAs, so the FP32 pipe is spent almost entirely on the matrix instruction.
-// SPLIT = d > 256: a second accumulator set holds the current k-block (rule 2).
+// SPLIT = d > 256 (kept as a template flag for the dispatcher; the k-block loop handles both).
 // VEC   = 16-byte aligned rows and d % 4 == 0.
 // ---------------------------------------------------------------------------------------------
 template <int CT, bool SPLIT, bool VEC>
@@ -107,21 +107,33 @@ __global__ __launch_bounds__(256, 2) void k_rotate_gemm(const float* __restrict_
 
     const int nslabs = (d + KB - 1) / KB;
 
-    // -- staging helpers: P slab -> registers -> LDS; x slab -> registers
+    // -- staging helpers: P slab -> registers -> LDS; x slab -> registers.
+    // Everything that depends only on (thread, i) is computed once: element offset of the
+    // thread's i-th float4 inside a slab (global and LDS) and whether its columns exist.
     f32x4 pst[NV];
+    int goff[NV], loff[NV], kk_[NV];
+    bool cok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + 256 * i;
+        const int kk = idx / (NC / 4), c4 = idx % (NC / 4);
+        kk_[i] = kk;
+        goff[i] = kk * d + col0 + 4 * c4;
+        loff[i] = kk * NC + 4 * c4;
+        cok[i] = col0 + 4 * c4 < d;
+    }
+    const float* pslab = Pm;  // advances by KB rows per slab
     auto load_p = [&](int slab) {
-        const int kb = slab * KB;
+        const int krem = d - slab * KB;  // rows of P left (wave-uniform)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = tid + 256 * i;
-            const int kk = idx / (NC / 4), c4 = idx % (NC / 4);
-            const int k = kb + kk, c = col0 + 4 * c4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < d) {
-                const float* p = Pm + (int64_t)k * d + c;
+            if (kk_[i] < krem) {
+                const float* p = pslab + goff[i];
                 if (VEC) {
-                    if (c < d) v = *reinterpret_cast<const f32x4*>(p);
+                    if (cok[i]) v = *reinterpret_cast<const f32x4*>(p);
                 } else {
+                    const int c = goff[i] - kk_[i] * d;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (c + e < d) v[e] = p[e];
@@ -129,14 +141,12 @@ __global__ __launch_bounds__(256, 2) void k_rotate_gemm(const float* __restrict_
             }
             pst[i] = v;
         }
+        pslab += (int64_t)KB * d;
     };
     auto store_p = [&](int buf) {
+        float* base = &ps[buf][0][0];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + 256 * i;
-            const int kk = idx / (NC / 4), c4 = idx % (NC / 4);
-            *reinterpret_cast<f32x4*>(&ps[buf][kk][4 * c4]) = pst[i];
-        }
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(base + loff[i]) = pst[i];
     };
     // each lane fetches only the k = 2s + h elements of its row that it feeds to the MFMA
     auto load_x = [&](int slab, float (&xv)[KB / 2]) {
@@ -151,56 +161,49 @@ __global__ __launch_bounds__(256, 2) void k_rotate_gemm(const float* __restrict_
     store_p(0);
     __syncthreads();
 
-    for (int slab = 0; slab < nslabs; ++slab) {
-        const int buf = slab & 1;
-        const bool more = slab + 1 < nslabs;
-        if (more) { load_p(slab + 1); load_x(slab + 1, xn); }
-
-        if (SPLIT && slab > 0 && (slab % (kKC / KB)) == 0) {
-            // rule 2: a k-block ended -> fold it (first block: plain copy) and restart the chains
+    // rule 2: the k range is cut into blocks of kKC; inside a block every output element is one
+    // fmaf chain (accumulated in `cur`), blocks are summed into `tot` with one rounded add each.
+    // (Nested loops keep the slab loop free of accumulator copies.)
+    constexpr int SPB = kKC / KB;  // slabs per block
+    for (int sb = 0; sb < nslabs; sb += SPB) {
+        const int se = (sb + SPB < nslabs) ? sb + SPB : nslabs;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                if (slab == kKC / KB) tot[ct] = cur[ct];
-                else
+        for (int ct = 0; ct < CT; ++ct) cur[ct] = zero;
+        for (int slab = sb; slab < se; ++slab) {
+            const int buf = slab & 1;
+            const bool more = slab + 1 < nslabs;
+            if (more) { load_p(slab + 1); load_x(slab + 1, xn); }
+            // B fragments are fetched one k-step ahead (two register sets), so a ds_read's
+            // latency sits behind the five MFMAs of the step before it instead of in front
+            float bf[2][CT];
+            {
+                const float* prow = &ps[buf][h][cbase];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) tot[ct][r] = fadd(tot[ct][r], cur[ct][r]);
-                cur[ct] = zero;
+                for (int ct = 0; ct < CT; ++ct) bf[0][ct] = prow[ct * 32];
             }
-        }
-        // B fragments are fetched one k-step ahead (two register sets), so a ds_read's latency
-        // sits behind the five MFMAs of the step before it instead of in front of its own
-        float bf[2][CT];
-        {
-            const float* prow = &ps[buf][h][cbase];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) bf[0][ct] = prow[ct * 32];
-        }
+            for (int s = 0; s < KB / 2; ++s) {
+                const float av = xv[s];
+                if (s + 1 < KB / 2) {
+                    const float* prow = &ps[buf][2 * (s + 1) + h][cbase];
 #pragma unroll
-        for (int s = 0; s < KB / 2; ++s) {
-            const float av = xv[s];
-            if (s + 1 < KB / 2) {
-                const float* prow = &ps[buf][2 * (s + 1) + h][cbase];
+                    for (int ct = 0; ct < CT; ++ct) bf[(s + 1) & 1][ct] = prow[ct * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this step's MFMAs
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) bf[(s + 1) & 1][ct] = prow[ct * 32];
+                for (int ct = 0; ct < CT; ++ct)
+                    cur[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[s & 1][ct], cur[ct], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this step's MFMAs
+            if (more) {
+                store_p(buf ^ 1);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                if (SPLIT) cur[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[s & 1][ct], cur[ct], 0, 0, 0);
-                else tot[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[s & 1][ct], tot[ct], 0, 0, 0);
+                for (int e = 0; e < KB / 2; ++e) xv[e] = xn[e];
             }
+            __syncthreads();
         }
-        if (more) {
-            store_p(buf ^ 1);
-#pragma unroll
-            for (int e = 0; e < KB / 2; ++e) xv[e] = xn[e];
-        }
-        __syncthreads();
-    }
-    if (SPLIT) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            if (nslabs <= kKC / KB) tot[ct] = cur[ct];
+            if (sb == 0) tot[ct] = cur[ct];
             else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tot[ct][r] = fadd(tot[ct][r], cur[ct][r]);
