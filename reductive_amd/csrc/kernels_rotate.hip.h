@@ -223,6 +223,131 @@ __global__ __launch_bounds__(256, 2) void k_rotate_gemm(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2/K4 v3  rotation GEMM, P-block stationary.
+// A workgroup keeps a 64-column block of Pm for ALL k in LDS (d x 64 floats, 76.8 KB at d = 300) and
+// streams 32-row tiles of x past it: per k-step a wave issues one ds_read2_b32 (both column
+// tiles' B fragments), half a global_load_dwordx4 (its row's x, the A operand) and two MFMAs,
+// so the FP32 pipe is spent almost entirely on the matrix instruction; the fixed per-tile work
+// (rule-2 fold, 32 stores) is amortised over 300 MFMAs.  The column blocks of one row range are
+// given to consecutive workgroups of ONE XCD so x is pulled from HBM once.
+// Rule 2 (k-blocks of 256) is honoured with one extra accumulator pair.
+// ---------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void k_rotate_pblock(const float* __restrict__ x, int64_t n,
+                                                          int64_t x_rs, const float* __restrict__ Pm,
+                                                          int d, float* __restrict__ out, int64_t o_rs,
+                                                          int rows_per_wg, int ncb, int64_t rg_per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) float pl[];  // [kpad][64]
+    const int kpad = (d + 3) & ~3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t q = b >> 3;
+    const int cb = (int)(q % ncb);
+    const int64_t rg_local = q / ncb;
+    const int64_t rg = rg_local * 8 + xcd;
+    const int col0 = cb * 64;
+
+    // stage the P block (zero padded beyond d in both directions)
+    for (int idx = tid; idx < kpad * 16; idx += 256) {
+        const int k = idx >> 4, c = col0 + 4 * (idx & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < d) {
+            const float* p = Pm + (int64_t)k * d + c;
+            if (VEC) {
+                if (c < d) v = *reinterpret_cast<const f32x4*>(p);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < d) v[e] = p[e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(&pl[(k << 6) + 4 * (idx & 15)]) = v;
+    }
+    __syncthreads();
+    if (rg_local >= rg_per_xcd) return;
+    const int64_t wg_row0 = rg * rows_per_wg;
+    if (wg_row0 >= n) return;
+    int64_t wg_row1 = wg_row0 + rows_per_wg;
+    if (wg_row1 > n) wg_row1 = n;
+
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                         0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* plane = pl + (h << 6) + j;  // + (2s) * 64 per k-step; +32 for the second tile
+    const int nq = kpad / 4;                 // groups of 4 k (two k-steps)
+    constexpr int QB = kKC / 4;              // groups per rule-2 block
+
+    for (int64_t row0 = wg_row0 + 32 * wave; row0 < wg_row1; row0 += 128) {
+        const int left = (int)((n - row0 < 32) ? n - row0 : 32);
+        const float* xr = x + ((j < left) ? row0 + j : n - 1) * x_rs;
+        auto load_x4 = [&](int qq) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (VEC) {
+                v = *reinterpret_cast<const f32x4*>(xr + 4 * qq);  // kpad == d when VEC (d % 4 == 0)
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * qq + e < d) v[e] = xr[4 * qq + e];
+            }
+            return v;
+        };
+        f32x16 tot0 = zero, tot1 = zero;
+        for (int qb = 0; qb < nq; qb += QB) {
+            const int qe = (qb + QB < nq) ? qb + QB : nq;
+            f32x16 c0 = zero, c1 = zero;
+            auto group = [&](int qq, const f32x4& xa) {
+                const float* p0 = plane + (4 * qq) * 64;
+                const float b00 = p0[0], b01 = p0[32], b10 = p0[128], b11 = p0[160];
+                const float a0 = h ? xa[1] : xa[0];
+                const float a1 = h ? xa[3] : xa[2];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b00, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b01, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b10, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b11, c1, 0, 0, 0);
+            };
+            // x is streamed through an 8-deep register ring: a group's 16 bytes are requested
+            // 32 MFMAs (~2,000 cycles) before they are used, which covers an HBM miss
+            constexpr int RD = 8;
+            f32x4 ring[RD];
+#pragma unroll
+            for (int u = 0; u < RD; ++u) ring[u] = (qb + u < qe) ? load_x4(qb + u) : f32x4{0.f, 0.f, 0.f, 0.f};
+            int q0 = qb;
+            for (; q0 + RD <= qe; q0 += RD) {
+#pragma unroll
+                for (int u = 0; u < RD; ++u) {
+                    const f32x4 xa = ring[u];
+                    if (q0 + RD + u < qe) ring[u] = load_x4(q0 + RD + u);
+                    group(q0 + u, xa);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RD; ++u)
+                if (q0 + u < qe) group(q0 + u, ring[u]);
+            if (qb == 0) { tot0 = c0; tot1 = c1; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { tot0[r] = fadd(tot0[r], c0[r]); tot1[r] = fadd(tot1[r], c1[r]); }
+            }
+        }
+        const int cA = col0 + j, cB = col0 + 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (rr < left) {
+                float* o = out + (row0 + rr) * o_rs;
+                if (cA < d) __builtin_nontemporal_store(tot0[r], o + cA);
+                if (cB < d) __builtin_nontemporal_store(tot1[r], o + cB);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Device self-test of the MFMA == fmaf-chain property (pqhip_selftest_mfma_chain).
 // One wave per trial: random A[32][k], B[k][32]; compares the MFMA tile with a scalar chain.
 // ---------------------------------------------------------------------------------------------

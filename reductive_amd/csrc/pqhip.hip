@@ -47,7 +47,7 @@ thread_local std::string g_hip_err;
     } while (0)
 
 constexpr int64_t kStageRows = 1 << 16;      // rows per staging buffer (host-resident calls)
-constexpr int64_t kScratchRowsMax = 1 << 20;  // rows per OPQ scratch chunk (device calls)
+constexpr int64_t kScratchBytesMax = 16ll << 30;  // OPQ scratch per device: up to 16 GB of the 288 GB HBM
 
 struct Staging {
     void* h_in = nullptr;   // pinned
@@ -203,14 +203,27 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
 {
     if (n == 0) return PQHIP_OK;
     const bool vec = (d % 4 == 0) && (x_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
+    const int kpad = (d + 3) & ~3;
+    const size_t pblock_bytes = (size_t)kpad * 64 * sizeof(float);
+    if (pblock_bytes <= 80 * 1024) {
+        // P-block stationary kernel: 64 columns of Pm for all k live in LDS (2 workgroups per CU)
+        const int rows_per_wg = 2048;
+        const int ncb = (d + 63) / 64;
+        const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
+        const int64_t rg_per_xcd = (n_rg + 7) / 8;
+        const dim3 grid((unsigned)(rg_per_xcd * ncb * 8));
+        static bool attr_set[2] = {false, false};
+        if (vec) {
+            if (!attr_set[1]) { HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr_set[1] = true; }
+            hipLaunchKernelGGL((k_rotate_pblock<true>), grid, dim3(256), pblock_bytes, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, rg_per_xcd);
+        } else {
+            if (!attr_set[0]) { HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr_set[0] = true; }
+            hipLaunchKernelGGL((k_rotate_pblock<false>), grid, dim3(256), pblock_bytes, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, rg_per_xcd);
+        }
+        HIPCHK(hipGetLastError());
+        return PQHIP_OK;
+    }
     const bool split = d > kKC;
-    constexpr int CT = 5;                      // 320 columns per workgroup
-    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((d + 2 * CT * 32 - 1) / (2 * CT * 32)));
-#define LAUNCH_ROT(SP, VE) \
-    hipLaunchKernelGGL((k_rotate_gemm<CT, SP, VE>), grid, dim3(256), 0, st, d_x, n, x_rs, Pm, d, d_out, o_rs)
-    if (split) { if (vec) LAUNCH_ROT(true, true); else LAUNCH_ROT(true, false); }
-    else { if (vec) LAUNCH_ROT(false, true); else LAUNCH_ROT(false, false); }
-#undef LAUNCH_ROT
     HIPCHK(hipGetLastError());
     return PQHIP_OK;
 }
@@ -272,7 +285,7 @@ int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_
 {
     if (!cb->has_proj) return encode_plain_dev(cb, slot, d_x, n, x_rs, d_codes, code_bytes, o_rs, st);
     // OPQ (pq.rs:276): rx = x.dot(P) into scratch, chunked, then PQ encode of rx
-    const int64_t chunk = std::min<int64_t>(n, kScratchRowsMax);
+    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
     PQCHK(ensure_scratch(cb, slot, chunk));
     CodebookDev& cd = cb->dev[slot];
     HIPCHK(hipStreamWaitEvent(st, cd.scratch_done, 0));
@@ -291,7 +304,7 @@ int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, 
 {
     if (!cb->has_proj) return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st);
     // OPQ (pq.rs:323-326): gather into scratch, then out = r.dot(P^T)
-    const int64_t chunk = std::min<int64_t>(n, kScratchRowsMax);
+    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
     PQCHK(ensure_scratch(cb, slot, chunk));
     CodebookDev& cd = cb->dev[slot];
     HIPCHK(hipStreamWaitEvent(st, cd.scratch_done, 0));
