@@ -331,3 +331,33 @@ def test_statistical_roundtrip_loss(ra, kats):
     rec = pq.reconstruct_batch(pq.quantize_batch(x))
     loss = np.sqrt(((x - rec) ** 2).sum(1)).mean()
     assert loss < st["loss_bound"]
+
+
+def test_shape_sweep_all_kernel_instantiations(ra):
+    """Every (T, DP, vec/scalar-load) instantiation of the three MFMA kernels plus odd shapes:
+    seeded random (M, K, dsub, n), codes must equal the oracle's for every variant."""
+    rng = np.random.RandomState(12345)
+    shapes = []
+    for K in (1, 2, 31, 32, 33, 64, 65, 128, 129, 255, 256):        # T = 1, 2, 4, 8 with padding
+        for dsub in (1, 2, 3, 4, 5, 8, 11, 12, 16, 17, 20, 24, 27, 28, 31, 32):
+            shapes.append((int(rng.randint(1, 4)), K, dsub, int(rng.randint(1, 200))))
+    rng.shuffle(shapes)
+    shapes = shapes[:72]
+    for i, (M, K, dsub, n) in enumerate(shapes):
+        q = synth.normalish(5000 + i, (M, K, dsub))
+        x = synth.normalish(6000 + i, (n, M * dsub))
+        want = orc.quantize_batch(q, x)
+        for variant in (0, 2, 3):
+            got = _pq(ra, q, variant=variant).quantize_batch(x)
+            assert got.tobytes() == want.tobytes(), (M, K, dsub, n, variant)
+    # unaligned device rows (row stride not a multiple of 4 floats) -> scalar-load instantiation
+    import torch
+    M, K, dsub = 3, 64, 8
+    q = synth.normalish(7001, (M, K, dsub))
+    wide = torch.from_numpy(synth.normalish(7002, (500, M * dsub + 3))).cuda()
+    view = wide[:, 1:1 + M * dsub]
+    pq = _pq(ra, q)
+    got = pq.quantize_batch_device(view)
+    assert "scalar-load" in pq.last_encode_kernel()
+    want = orc.quantize_batch(q, view.cpu().numpy())
+    assert got.cpu().numpy().tobytes() == want.tobytes()
