@@ -101,6 +101,17 @@ __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b)
     return r;
 }
 
+
+// lane-half select: lanes 32..63 take `hi`, lanes 0..31 take `lo`.  The two values are first made
+// opaque so that the optimiser cannot turn selects on vector elements into a runtime-indexed
+// extract (which it lowers to a compare/select chain over the whole vector); the select itself is
+// left to the compiler so that it also inserts the VALU -> MFMA operand wait states.
+__device__ __forceinline__ float sel_half(float lo, float hi)
+{
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return (threadIdx.x & 32) ? hi : lo;
+}
+
 // rule 1 (ndarray unrolled_dot(x, x)) for a register vector of compile-time length D held as D/2
 // pairs, with packed arithmetic: identical roundings, about half the instructions of the scalar form.
 template <int D>

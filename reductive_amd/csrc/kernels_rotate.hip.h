@@ -300,34 +300,50 @@ __global__ __launch_bounds__(256, 2) void k_rotate_pblock(const float* __restric
         for (int qb = 0; qb < nq; qb += QB) {
             const int qe = (qb + QB < nq) ? qb + QB : nq;
             f32x16 c0 = zero, c1 = zero;
-            auto group = [&](int qq, const f32x4& xa) {
-                const float* p0 = plane + (4 * qq) * 64;
-                const float b00 = p0[0], b01 = p0[32], b10 = p0[128], b11 = p0[160];
-                const float a0 = h ? xa[1] : xa[0];
-                const float a1 = h ? xa[3] : xa[2];
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b00, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b01, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b10, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b11, c1, 0, 0, 0);
-            };
-            // x is streamed through an 8-deep register ring: a group's 16 bytes are requested
-            // 32 MFMAs (~2,000 cycles) before they are used, which covers an HBM miss
+            // One "group" = 4 k = two k-steps = four MFMAs.  x is streamed through an 8-deep register
+            // ring: a group's 16 bytes are requested 32 MFMAs (~2,000 cycles) before they are used;
+            // all ring loads are unconditional (indices clamped) so the compiler can count vmcnt across
+            // the loop instead of draining it.  B fragments are read one group ahead.
             constexpr int RD = 8;
+            const int qlast = qe - 1;
             f32x4 ring[RD];
 #pragma unroll
-            for (int u = 0; u < RD; ++u) ring[u] = (qb + u < qe) ? load_x4(qb + u) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < RD; ++u) ring[u] = load_x4((qb + u < qlast) ? qb + u : qlast);
+            float bn[4];
+            auto read_b = [&](int qq, float (&bb)[4]) {
+                const float* p0 = plane + (4 * qq) * 64;
+                bb[0] = p0[0]; bb[1] = p0[32]; bb[2] = p0[128]; bb[3] = p0[160];
+            };
+            read_b(qb, bn);
             int q0 = qb;
             for (; q0 + RD <= qe; q0 += RD) {
 #pragma unroll
                 for (int u = 0; u < RD; ++u) {
-                    const f32x4 xa = ring[u];
-                    if (q0 + RD + u < qe) ring[u] = load_x4(q0 + RD + u);
-                    group(q0 + u, xa);
+                    const int qq = q0 + u;
+                    const float a0 = sel_half(ring[u][0], ring[u][1]);
+                    const float a1 = sel_half(ring[u][2], ring[u][3]);
+                    const float b0 = bn[0], b1 = bn[1], b2 = bn[2], b3 = bn[3];
+                    ring[u] = load_x4((qq + RD < qlast) ? qq + RD : qlast);
+                    read_b((qq + 1 < qlast) ? qq + 1 : qlast, bn);
+                    __builtin_amdgcn_sched_barrier(0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, c1, 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < RD; ++u)
-                if (q0 + u < qe) group(q0 + u, ring[u]);
+            // tail (< RD groups of this k-block): plain loads; `bn` already holds group q0's fragments
+            for (int qq = q0; qq < qe; ++qq) {
+                const f32x4 xa = load_x4(qq);
+                const float a0 = sel_half(xa[0], xa[1]);
+                const float a1 = sel_half(xa[2], xa[3]);
+                const float b0 = bn[0], b1 = bn[1], b2 = bn[2], b3 = bn[3];
+                read_b((qq + 1 < qlast) ? qq + 1 : qlast, bn);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, c1, 0, 0, 0);
+            }
             if (qb == 0) { tot0 = c0; tot1 = c1; }
             else {
 #pragma unroll

@@ -215,6 +215,11 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         static bool attr_set[2] = {false, false};
         if (vec) {
             if (!attr_set[1]) { HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr_set[1] = true; }
+            if (getenv("PQHIP_DEBUG_OCC")) {
+                int nb = -1;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_rotate_pblock<true>, 256, pblock_bytes);
+                fprintf(stderr, "[pqhip] k_rotate_pblock: %d blocks/CU at %zu B dynamic LDS\n", nb, pblock_bytes);
+            }
             hipLaunchKernelGGL((k_rotate_pblock<true>), grid, dim3(256), pblock_bytes, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, rg_per_xcd);
         } else {
             if (!attr_set[0]) { HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr_set[0] = true; }
