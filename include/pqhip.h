@@ -115,6 +115,18 @@ int32_t pqhip_reconstruct_batch_f32_dev(pqhip_codebook *cb, int32_t device_slot,
  * device call since the last query saw a code >= K (synchronises `stream`). */
 int32_t pqhip_check_codes_dev(pqhip_codebook *cb, int32_t device_slot, void *stream);
 
+/*
+ * "Next" row of the hot path: the assignment step of k-means training,
+ * `kmeans::cluster_assignments(centroids, instances, Axis(0))` (src/kmeans.rs:133-159, called from
+ * kmeans.rs:319 and through primitives::quantize_batch::<_, usize, _> at opq.rs:180).  Same kernels
+ * as PQ encode with one subquantizer; out[i] = index of the nearest of the K centroids [K][dim] for
+ * row i of x, as out_bytes-wide unsigned integers (8 = usize).  Host buffers, element strides.
+ */
+int32_t pqhip_cluster_assignments_f32(pqhip_ctx *ctx, const float *centroids, int64_t n_centroids,
+                                      int64_t dim, const float *x, int64_t n_rows,
+                                      int64_t x_row_stride, int64_t x_col_stride, void *out,
+                                      int32_t out_bytes);
+
 /* ---- knobs used by the test-suite and the bench (not part of the reference surface) -------- */
 /* force a kernel variant for encode: 0 = auto, 1 = scalar VALU anchor kernel,
  * 2 = MFMA kernel with VALU argmin, 3 = MFMA + LDS-atomic argmin with register-resident codebook

@@ -86,6 +86,8 @@ def lib():
     L.pqhip_reconstruct_batch_f32_dev.argtypes = [vp, i32, vp, i32, i64, i64, vp, i64, vp]
     L.pqhip_check_codes_dev.restype = i32
     L.pqhip_check_codes_dev.argtypes = [vp, i32, vp]
+    L.pqhip_cluster_assignments_f32.restype = i32
+    L.pqhip_cluster_assignments_f32.argtypes = [vp, fp, i64, i64, vp, i64, i64, i64, vp, i32]
     L.pqhip_set_encode_variant.restype = i32
     L.pqhip_set_encode_variant.argtypes = [vp, i32]
     L.pqhip_last_encode_kernel.restype = ctypes.c_char_p
@@ -105,5 +107,6 @@ EXPORTS = [
     "pqhip_codebook_reconstructed_len", "pqhip_codebook_n_centroids",
     "pqhip_codebook_has_projection", "pqhip_quantize_batch_f32", "pqhip_reconstruct_batch_f32",
     "pqhip_quantize_batch_f32_dev", "pqhip_reconstruct_batch_f32_dev", "pqhip_check_codes_dev",
+    "pqhip_cluster_assignments_f32",
     "pqhip_set_encode_variant", "pqhip_last_encode_kernel", "pqhip_selftest_mfma_chain",
 ]

@@ -17,9 +17,16 @@ static unsigned debug_lds_pad()
 }
 
 template <int KIND, int T, int DP>
-static void launch_vec(bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
+static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st)
 {
     const unsigned pad = debug_lds_pad();
+    if (code_bytes == 4) {
+        if (KIND != 2) return false;
+        if (vec) hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, true, uint32_t>), grid, dim3(256), pad, st, a);
+        else hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, false, uint32_t>), grid, dim3(256), pad, st, a);
+        return true;
+    }
+    if (code_bytes != 1) return false;
     if (KIND == 0) {
         if (vec) hipLaunchKernelGGL((k_encode_mfma<T, DP, true, uint8_t>), grid, dim3(256), pad, st, a);
         else hipLaunchKernelGGL((k_encode_mfma<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
@@ -30,24 +37,25 @@ static void launch_vec(bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
         if (vec) hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, true, uint8_t>), grid, dim3(256), pad, st, a);
         else hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
     }
+    return true;
 }
 
 template <int KIND, int T>
-bool launch_encode_mfma_t(int DP, bool vec, const EncodeArgs& a, dim3 grid, hipStream_t st)
+bool launch_encode_mfma_t(int DP, bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st)
 {
     switch (DP) {
-    case 4: launch_vec<KIND, T, 4>(vec, a, grid, st); return true;
-    case 8: launch_vec<KIND, T, 8>(vec, a, grid, st); return true;
-    case 12: launch_vec<KIND, T, 12>(vec, a, grid, st); return true;
-    case 16: launch_vec<KIND, T, 16>(vec, a, grid, st); return true;
-    case 20: launch_vec<KIND, T, 20>(vec, a, grid, st); return true;
-    case 24: launch_vec<KIND, T, 24>(vec, a, grid, st); return true;
-    case 28: launch_vec<KIND, T, 28>(vec, a, grid, st); return true;
-    case 32: launch_vec<KIND, T, 32>(vec, a, grid, st); return true;
+    case 4: return launch_vec<KIND, T, 4>(vec, code_bytes, a, grid, st);
+    case 8: return launch_vec<KIND, T, 8>(vec, code_bytes, a, grid, st);
+    case 12: return launch_vec<KIND, T, 12>(vec, code_bytes, a, grid, st);
+    case 16: return launch_vec<KIND, T, 16>(vec, code_bytes, a, grid, st);
+    case 20: return launch_vec<KIND, T, 20>(vec, code_bytes, a, grid, st);
+    case 24: return launch_vec<KIND, T, 24>(vec, code_bytes, a, grid, st);
+    case 28: return launch_vec<KIND, T, 28>(vec, code_bytes, a, grid, st);
+    case 32: return launch_vec<KIND, T, 32>(vec, code_bytes, a, grid, st);
     default: return false;
     }
 }
 
-template bool launch_encode_mfma_t<PQ_KIND, PQ_T>(int, bool, const EncodeArgs&, dim3, hipStream_t);
+template bool launch_encode_mfma_t<PQ_KIND, PQ_T>(int, bool, int, const EncodeArgs&, dim3, hipStream_t);
 
 }  // namespace pqhip

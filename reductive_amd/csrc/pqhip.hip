@@ -137,8 +137,10 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
 {
     if (n == 0) return PQHIP_OK;
     CodebookDev& cd = cb->dev[slot];
-    // the MFMA kernel emits u8 codes (K <= 256); 32-bit codes take the anchor kernel for now
-    const bool mfma_possible = cb->T != 0 && cb->norms_ok && code_bytes == 1;
+    // MFMA kernels: u8 codes from every variant, u32 codes (k-means assignments, wide index types)
+    // from the default variant; K <= 256 either way
+    const bool mfma_possible = cb->T != 0 && cb->norms_ok &&
+                               (code_bytes == 1 || (code_bytes == 4 && (cb->variant == 0 || cb->variant == 4)));
     bool use_mfma = mfma_possible;
     if (cb->variant == 1) use_mfma = false;
     if (cb->variant >= 2 && !mfma_possible) return PQHIP_EUNSUPPORTED;
@@ -172,7 +174,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         }
         const bool vec = (cb->dsub % 4 == 0) && (cb->DP == cb->dsub) && (x_rs % 4 == 0) &&
                          ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
-        if (!launch_encode_mfma(kind, cb->T, cb->DP, vec, a, grid, st)) return PQHIP_EUNSUPPORTED;
+        if (!launch_encode_mfma(kind, cb->T, cb->DP, vec, code_bytes, a, grid, st)) return PQHIP_EUNSUPPORTED;
         static const char* const names[3][2] = {{"k_encode_mfma<scalar-load>", "k_encode_mfma<vec4>"},
                                                 {"k_encode_mfma_lds<scalar-load>", "k_encode_mfma_lds<vec4>"},
                                                 {"k_encode_mfma_lds3<scalar-load>", "k_encode_mfma_lds3<vec4>"}};
@@ -724,6 +726,18 @@ int32_t pqhip_reconstruct_batch_f32(pqhip_codebook* cb, const void* codes, int32
             if (pend_rows[k]) PQCHK(drain(k, pend_r0[k], pend_rows[k]));
         return range_err ? PQHIP_ECODE_RANGE : PQHIP_OK;
     });
+}
+
+int32_t pqhip_cluster_assignments_f32(pqhip_ctx* ctx, const float* centroids, int64_t n_centroids,
+                                      int64_t dim, const float* x, int64_t n_rows, int64_t x_rs,
+                                      int64_t x_cs, void* out, int32_t out_bytes)
+{
+    if (!ctx || !centroids) return PQHIP_EINVAL;
+    pqhip_codebook* cb = nullptr;
+    PQCHK(pqhip_codebook_create(ctx, centroids, 1, n_centroids, dim, nullptr, &cb));
+    const int32_t rc = pqhip_quantize_batch_f32(cb, x, n_rows, x_rs, x_cs, out, out_bytes, 1, 1);
+    pqhip_codebook_destroy(cb);
+    return rc;
 }
 
 int32_t pqhip_selftest_mfma_chain(pqhip_ctx* ctx, int32_t slot, int32_t k, int32_t n_trials,

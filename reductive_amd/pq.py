@@ -87,6 +87,31 @@ def _first_min(d):
     return int(np.flatnonzero(ok & (d == d[ok].min()))[0])
 
 
+def cluster_assignments(centroids, instances, dtype=np.uint64, ctx=None):
+    """`kmeans::cluster_assignments(centroids, instances, Axis(0))` (src/kmeans.rs:133-159) on the
+    GPU: index of the nearest centroid [K, dim] for every row of `instances` [n, dim]."""
+    centroids = np.ascontiguousarray(centroids, dtype=np.float32)
+    x = np.asarray(instances, dtype=np.float32)
+    if centroids.ndim != 2 or x.ndim != 2 or x.shape[1] != centroids.shape[1]:
+        raise PanicError("Cannot compute (squared) euclidean distance of matrices with different "
+                         "numbers of columns.")                                  # linalg.rs:161-165
+    out = np.zeros(x.shape[0], dtype=dtype)
+    if x.shape[0] == 0:
+        return out
+    if any(s < 0 for s in x.strides) or any(s % 4 for s in x.strides):
+        x = np.ascontiguousarray(x)
+    rs, cs = _estrides(x)
+    ctx = ctx or default_ctx()
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = _lib.lib().pqhip_cluster_assignments_f32(ctx.handle, centroids.ctypes.data_as(fp),
+                                                  centroids.shape[0], centroids.shape[1],
+                                                  x.ctypes.data, x.shape[0], rs, cs,
+                                                  out.ctypes.data, out.itemsize)
+    if rc != _lib.OK:
+        raise _lib.PqHipError(rc, "pqhip_cluster_assignments_f32")
+    return out
+
+
 class Pq:
     """Product quantizer (Jegou et al., 2011) -- mirror of `reductive::pq::Pq<f32>`."""
 

@@ -361,3 +361,32 @@ def test_shape_sweep_all_kernel_instantiations(ra):
     assert "scalar-load" in pq.last_encode_kernel()
     want = orc.quantize_batch(q, view.cpu().numpy())
     assert got.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_cluster_assignments_entry_point(ra, kats):
+    """the k-means assignment step (kmeans.rs:133-159) through its own C-ABI
+    entry point, usize-wide indices, MFMA kernel with 32-bit codes on the device path."""
+    import torch
+    k = kats["cluster_assignments"]
+    c = np.array(k["centroids"], np.float32)
+    x = np.array(k["instances"], np.float32)
+    assert ra.cluster_assignments(c, x).tolist() == k["assignments"]
+    assert ra.cluster_assignments(c, np.asfortranarray(x), dtype=np.uint32).tolist() == k["assignments"]
+    for (K, dim, n) in [(256, 20, 5000), (128, 2, 3000), (300, 8, 500), (17, 33, 257)]:
+        cen = synth.normalish(8100 + K, (K, dim))
+        xs = synth.normalish(8200 + K, (n, dim))
+        want = orc.cluster_assignments(cen, xs)
+        assert ra.cluster_assignments(cen, xs).tolist() == want.tolist()
+    # device path with 32-bit codes runs the MFMA kernel
+    K, dim, n = 256, 20, 100_000
+    cen = synth.normalish(8301, (K, dim))
+    pq = ra.Pq(None, cen[None])
+    xd = torch.from_numpy(synth.normalish(8302, (n, dim))).cuda()
+    out = torch.empty((n, 1), dtype=torch.int32, device="cuda")
+    rc = ra.lib().pqhip_quantize_batch_f32_dev(pq._cb(), 0, xd.data_ptr(), n, dim, out.data_ptr(), 4, 1,
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert pq.last_encode_kernel().startswith("k_encode_mfma_lds3")
+    want = orc.cluster_assignments(cen, xd.cpu().numpy())
+    assert out[:, 0].cpu().numpy().tolist() == want.tolist()
