@@ -345,6 +345,28 @@ int32_t for_each_shard(pqhip_ctx* ctx, int64_t n, F fn)
     return PQHIP_OK;
 }
 
+// Host-side packing of strided rows into (and out of) the pinned staging buffers runs on a few
+// threads: one core moves ~10 GB/s, PCIe Gen5 x16 ~55 GB/s.
+template <typename F>
+void parallel_rows(int64_t rows, int max_threads, F fn)
+{
+    int nt = (int)std::min<int64_t>(max_threads, (rows + 4095) / 4096);
+    if (nt <= 1) { fn((int64_t)0, rows); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (rows + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t b = std::min<int64_t>(rows, t * per), e = std::min<int64_t>(rows, b + per);
+        if (b < e) th.emplace_back([=] { fn(b, e); });
+    }
+    for (auto& t : th) t.join();
+}
+
+int pack_threads(const pqhip_ctx* ctx)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (int)std::max<unsigned>(1, std::min<unsigned>(8, hw / (unsigned)std::max<size_t>(1, ctx->devs.size())));
+}
+
 void store_code(void* base, int bytes, int64_t off, uint32_t v)
 {
     switch (bytes) {
@@ -624,6 +646,7 @@ int32_t pqhip_quantize_batch_f32(pqhip_codebook* cb, const float* x, int64_t n, 
     if (code_bytes < 8 && (uint64_t)(cb->K - 1) > ((1ull << (8 * code_bytes)) - 1)) return PQHIP_EINDEX_WIDTH;
     const int dev_bytes = cb->K <= 256 ? 1 : 4;
     const int64_t d = cb->d, M = cb->M;
+    const int nthreads = pack_threads(cb->ctx);
 
     return for_each_shard(cb->ctx, n, [&](int slot, int64_t rb, int64_t re) -> int32_t {
         DeviceSlot& ds = *cb->ctx->devs[slot];
@@ -649,13 +672,15 @@ int32_t pqhip_quantize_batch_f32(pqhip_codebook* cb, const float* x, int64_t n, 
             const int64_t rows = std::min<int64_t>(cap, re - r0);
             if (pend_rows[b]) { PQCHK(drain(b, pend_r0[b], pend_rows[b])); pend_rows[b] = 0; }
             float* hin = (float*)ds.st[b].h_in;
-            if (x_cs == 1) {
-                for (int64_t i = 0; i < rows; ++i)
-                    std::memcpy(hin + i * d, x + (r0 + i) * x_rs, (size_t)d * sizeof(float));
-            } else {
-                for (int64_t i = 0; i < rows; ++i)
-                    for (int64_t k = 0; k < d; ++k) hin[i * d + k] = x[(r0 + i) * x_rs + k * x_cs];
-            }
+            parallel_rows(rows, nthreads, [&, r0, hin](int64_t ib, int64_t ie) {
+                if (x_cs == 1) {
+                    for (int64_t i = ib; i < ie; ++i)
+                        std::memcpy(hin + i * d, x + (r0 + i) * x_rs, (size_t)d * sizeof(float));
+                } else {
+                    for (int64_t i = ib; i < ie; ++i)
+                        for (int64_t k = 0; k < d; ++k) hin[i * d + k] = x[(r0 + i) * x_rs + k * x_cs];
+                }
+            });
             HIPCHK(hipMemcpyAsync(ds.st[b].d_in, hin, (size_t)rows * d * sizeof(float),
                                   hipMemcpyHostToDevice, ds.stream[b]));
             PQCHK(quantize_dev_impl(cb, slot, (const float*)ds.st[b].d_in, rows, d, ds.st[b].d_out,
@@ -680,6 +705,7 @@ int32_t pqhip_reconstruct_batch_f32(pqhip_codebook* cb, const void* codes, int32
     if (!codes || !out) return PQHIP_EINVAL;
     const int dev_bytes = code_bytes == 1 ? 1 : 4;
     const int64_t d = cb->d, M = cb->M;
+    const int nthreads = pack_threads(cb->ctx);
 
     return for_each_shard(cb->ctx, n, [&](int slot, int64_t rb, int64_t re) -> int32_t {
         DeviceSlot& ds = *cb->ctx->devs[slot];
@@ -691,13 +717,15 @@ int32_t pqhip_reconstruct_batch_f32(pqhip_codebook* cb, const void* codes, int32
         auto drain = [&](int b, int64_t r0, int64_t rows) -> int32_t {
             HIPCHK(hipStreamSynchronize(ds.stream[b]));
             const float* h = (const float*)ds.st[b].h_out;
-            if (o_cs == 1) {
-                for (int64_t i = 0; i < rows; ++i)
-                    std::memcpy(out + (r0 + i) * o_rs, h + i * d, (size_t)d * sizeof(float));
-            } else {
-                for (int64_t i = 0; i < rows; ++i)
-                    for (int64_t k = 0; k < d; ++k) out[(r0 + i) * o_rs + k * o_cs] = h[i * d + k];
-            }
+            parallel_rows(rows, nthreads, [&, r0, h](int64_t ib, int64_t ie) {
+                if (o_cs == 1) {
+                    for (int64_t i = ib; i < ie; ++i)
+                        std::memcpy(out + (r0 + i) * o_rs, h + i * d, (size_t)d * sizeof(float));
+                } else {
+                    for (int64_t i = ib; i < ie; ++i)
+                        for (int64_t k = 0; k < d; ++k) out[(r0 + i) * o_rs + k * o_cs] = h[i * d + k];
+                }
+            });
             return PQHIP_OK;
         };
         int64_t pend_r0[2] = {0, 0}, pend_rows[2] = {0, 0};
