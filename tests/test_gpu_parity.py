@@ -390,3 +390,34 @@ def test_cluster_assignments_entry_point(ra, kats):
     assert pq.last_encode_kernel().startswith("k_encode_mfma_lds3")
     want = orc.cluster_assignments(cen, xd.cpu().numpy())
     assert out[:, 0].cpu().numpy().tolist() == want.tolist()
+
+
+def test_device_api_streams_and_opq_scratch_ordering(ra):
+    """Device entry points are asynchronous on the caller's stream; two streams sharing one OPQ
+    codebook must serialise on its scratch buffer (event-ordered), results unchanged."""
+    import torch
+    M, K, dsub = 8, 64, 8
+    d = M * dsub
+    q = synth.normalish(9101, (M, K, dsub))
+    P = synth.orthonormal(9102, d)
+    pq = _pq(ra, q, P)
+    xs = [torch.from_numpy(synth.normalish(9110 + i, (20000 + 777 * i, d))).cuda() for i in range(4)]
+    wants = [orc.quantize_batch(q, x.cpu().numpy(), projection=P, n_threads=8) for x in xs]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = []
+    torch.cuda.synchronize()
+    for i, x in enumerate(xs):
+        with torch.cuda.stream(streams[i % 2]):
+            outs.append(pq.quantize_batch_device(x))
+    torch.cuda.synchronize()
+    for o, w in zip(outs, wants):
+        assert o.cpu().numpy().tobytes() == w.tobytes()
+    # reconstruct through the same scratch
+    recs = []
+    for i, o in enumerate(outs):
+        with torch.cuda.stream(streams[i % 2]):
+            recs.append(pq.reconstruct_batch_device(o, check=(i == 3)))
+    torch.cuda.synchronize()
+    for r, w in zip(recs, wants):
+        ref = orc.reconstruct_batch(q, w, projection=P)
+        assert np.abs(r.cpu().numpy() - ref).max() <= REL_TOL * np.abs(ref).max()
