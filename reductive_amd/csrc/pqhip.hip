@@ -262,20 +262,22 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     const bool vec = (cb->dsub % 4 == 0) && (o_rs % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
     const int cpr = vec ? d / 4 : d;
-    // rows per block: as many as keep rows*cpr < 2^16 and the magic division exact (<= 64)
+    // rows per block: as many as keep rows*cpr < 2^16, the magic division exact and the block's
+    // codes within 16 elements per thread (<= 64)
     int rows_per_block = 64;
     unsigned inv_cpr = 0;
     for (;; rows_per_block /= 2) {
         inv_cpr = (unsigned)((65536 + cpr - 1) / cpr);
-        bool exact = (int64_t)rows_per_block * cpr < 65536;
+        bool exact = (int64_t)rows_per_block * cpr < 65536 && (int64_t)rows_per_block * cb->M <= 256 * 16;
         for (int L = 0; exact && L < rows_per_block * cpr; ++L)
             exact = (int)(((unsigned)L * inv_cpr) >> 16) == L / cpr;
         if (exact || rows_per_block == 1) break;
     }
+    if (cb->M > 256 * 16) return PQHIP_EUNSUPPORTED;
     if ((int64_t)cpr >= 65536) return PQHIP_EUNSUPPORTED;
     const unsigned grid =
         (unsigned)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, 256 * 8);
-    const size_t lds = (size_t)cpr * sizeof(int);
+    const size_t lds = (((size_t)cpr * sizeof(int) + 15) & ~(size_t)15) + 2 * (size_t)rows_per_block * cb->M * code_bytes;
 #define LAUNCH_REC(IDX, V)                                                                        \
     hipLaunchKernelGGL((k_reconstruct<IDX, V>), dim3(grid), dim3(256), lds, st,                   \
                        (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K,  \
