@@ -421,3 +421,31 @@ def test_device_api_streams_and_opq_scratch_ordering(ra):
     for r, w in zip(recs, wants):
         ref = orc.reconstruct_batch(q, w, projection=P)
         assert np.abs(r.cpu().numpy() - ref).max() <= REL_TOL * np.abs(ref).max()
+
+
+def test_trained_codebook_and_opq_at_scale(ra):
+    """Realistic data: U[0,1) vectors, a codebook refined by Lloyd steps (assignment on the GPU,
+    centroid update in numpy -- training itself is out of scope), 400k x 300 PQ and 150k x 300
+    OPQ batches compared code-for-code with the oracle (natural near-ties included)."""
+    M, K, dsub = 15, 256, 20
+    d = M * dsub
+    x = synth.uniform01(9201, (400_000, d))
+    q = np.stack([x[m * 1000:m * 1000 + K, m * dsub:(m + 1) * dsub] for m in range(M)]).astype(np.float32).copy()
+    for _ in range(3):
+        codes = ra.Pq(None, q).quantize_batch(x[:50_000])
+        for m in range(M):
+            sub = x[:50_000, m * dsub:(m + 1) * dsub]
+            for j in np.unique(codes[:, m]):
+                q[m, j] = sub[codes[:, m] == j].mean(0)
+    want = orc.quantize_batch(q, x, n_threads=16)
+    for variant in (0, 3):
+        got = _pq(ra, q, variant=variant).quantize_batch(x)
+        assert got.tobytes() == want.tobytes(), variant
+    P = synth.orthonormal(9202, d)
+    xo = x[:150_000]
+    want_o = orc.quantize_batch(q, xo, projection=P, n_threads=16)
+    pq = _pq(ra, q, P)
+    assert pq.quantize_batch(xo).tobytes() == want_o.tobytes()
+    rec = pq.reconstruct_batch(want_o[:20_000])
+    ref = orc.reconstruct_batch(q, want_o[:20_000], projection=P)
+    assert np.abs(rec - ref).max() <= REL_TOL * np.abs(ref).max()
