@@ -197,7 +197,7 @@ def main():
                 ach = flop * rows / sec / 1e12
                 rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                                   "kernel": extra["encode_kernel"] if args.workload == "encode" else "k_rotate_pblock + " + extra["encode_kernel"],
+                                   "kernel": extra["encode_kernel"] if args.workload == "encode" else "k_rotate_pblock5 + " + extra["encode_kernel"],
                                    "avg_launch_ms": kernel_ms, "algorithmic_flop_per_vector": flop,
                                    "algorithmic_bytes_per_vector": BYTES_PER_VEC,
                                    "hbm_gbs": BYTES_PER_VEC * rows / sec / 1e9,

@@ -6,64 +6,6 @@
 namespace pqhip {
 
 // ---------------------------------------------------------------------------------------------
-// K2/K4  rotation GEMM   out[n][c] = sum_k x[n][k] * Pm[k][c]     (pq.rs:276, pq.rs:324)
-// with the matrixmultiply k-blocking of rule 2: chain(0..255) + chain(256..511) + ...
-// Wave tile 32 rows x 64 columns (two 32x32 accumulators + two more for the current k-block),
-// workgroup = 4 waves stacked on rows.  x is the A operand (row on the lane, k on the
-// half-wave), Pm the B operand (coalesced 128-B rows).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_rotate_mfma(const float* __restrict__ x, int64_t n,
-                                                        int64_t x_rs,
-                                                        const float* __restrict__ Pm, int d,
-                                                        float* __restrict__ out, int64_t o_rs)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-    if (row0 >= n) return;
-    const int c0 = blockIdx.y * 64;
-
-    int64_t arow = row0 + j;
-    if (arow >= n) arow = n - 1;
-    const float* xr = x + arow * x_rs;
-    const int cA = c0 + j, cB = c0 + 32 + j;
-    const bool okA = cA < d, okB = cB < d;
-
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
-                         0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 totA = zero, totB = zero;
-    for (int kb = 0; kb < d; kb += kKC) {
-        const int ke = (kb + kKC < d) ? kb + kKC : d;
-        f32x16 accA = zero, accB = zero;
-        for (int k0 = kb; k0 < ke; k0 += 2) {
-            const int k = k0 + h;
-            const bool kok = k < ke;
-            const float av = kok ? xr[k] : 0.f;
-            const float* prow = Pm + (int64_t)(kok ? k : 0) * d;
-            const float bA = (kok && okA) ? prow[cA] : 0.f;
-            const float bB = (kok && okB) ? prow[cB] : 0.f;
-            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bA, accA, 0, 0, 0);
-            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bB, accB, 0, 0, 0);
-        }
-        if (kb == 0) {
-            totA = accA; totB = accB;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { totA[r] = fadd(totA[r], accA[r]); totB[r] = fadd(totB[r], accB[r]); }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < n) {
-            if (okA) out[row * o_rs + cA] = totA[r];
-            if (okB) out[row * o_rs + cB] = totB[r];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // K2/K4 v2  rotation GEMM with LDS-staged P slabs.
 //   out[n][c] = sum_k x[n][k] * Pm[k][c], rule-2 chains (restart every 256 k, blocks summed).
 // Workgroup = 4 waves = 64 rows x (2 * CT * 32) columns; wave (rg, ch) owns 32 rows x CT column
@@ -253,9 +195,12 @@ __global__ __launch_bounds__(256, 2) void k_rotate_pblock(const float* __restric
     const int64_t rg = rg_local * 8 + xcd;
     const int col0 = cb * 64;
 
-    // stage the P block (zero padded beyond d in both directions)
+    // stage the P block (zero padded beyond d in both directions).  LDS image: [k / 4][col][4] with the
+    // four k of a group stored in the order (0, 2, 1, 3): lane half h then finds its two operands of
+    // the group, k = 4q + h and k = 4q + 2 + h, as ONE 8-byte word at [q][col][2h] (one ds_read_b64 per
+    // column tile and group, addressed by immediate offsets).
     for (int idx = tid; idx < kpad * 16; idx += 256) {
-        const int k = idx >> 4, c = col0 + 4 * (idx & 15);
+        const int k = idx >> 4, c4 = idx & 15, c = col0 + 4 * c4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (k < d) {
             const float* p = Pm + (int64_t)k * d + c;
@@ -267,7 +212,10 @@ __global__ __launch_bounds__(256, 2) void k_rotate_pblock(const float* __restric
                     if (c + e < d) v[e] = p[e];
             }
         }
-        *reinterpret_cast<f32x4*>(&pl[(k << 6) + 4 * (idx & 15)]) = v;
+        const int inner = ((k & 1) << 1) | ((k >> 1) & 1);
+        float* dst = pl + ((((k >> 2) << 6) + 4 * c4) << 2) + inner;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * e] = v[e];
     }
     __syncthreads();
     if (rg_local >= rg_per_xcd) return;
@@ -278,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void k_rotate_pblock(const float* __restric
 
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                          0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* plane = pl + (h << 6) + j;  // + (2s) * 64 per k-step; +32 for the second tile
+    const float* plane = pl + 4 * j + 2 * h;  // + q * 256 floats per group; + 128 for the second column tile
     const int nq = kpad / 4;                 // groups of 4 k (two k-steps)
     constexpr int QB = kKC / 4;              // groups per rule-2 block
 
@@ -301,50 +249,196 @@ __global__ __launch_bounds__(256, 2) void k_rotate_pblock(const float* __restric
             const int qe = (qb + QB < nq) ? qb + QB : nq;
             f32x16 c0 = zero, c1 = zero;
             // One "group" = 4 k = two k-steps = four MFMAs.  x is streamed through an 8-deep register
-            // ring: a group's 16 bytes are requested 32 MFMAs (~2,000 cycles) before they are used;
-            // all ring loads are unconditional (indices clamped) so the compiler can count vmcnt across
-            // the loop instead of draining it.  B fragments are read one group ahead.
+            // ring (a group's 16 bytes are requested 32 MFMAs before they are used; loads unconditional
+            // so the compiler counts vmcnt across the loop); B operands are read one group ahead as
+            // 8-byte words.  Steady-state chunks carry no index clamps and address everything by
+            // immediate offsets: per group 1 global load, 2 LDS reads, 2 lane-half selects, 4 MFMAs.
             constexpr int RD = 8;
             const int qlast = qe - 1;
             f32x4 ring[RD];
 #pragma unroll
             for (int u = 0; u < RD; ++u) ring[u] = load_x4((qb + u < qlast) ? qb + u : qlast);
-            float bn[4];
-            auto read_b = [&](int qq, float (&bb)[4]) {
-                const float* p0 = plane + (4 * qq) * 64;
-                bb[0] = p0[0]; bb[1] = p0[32]; bb[2] = p0[128]; bb[3] = p0[160];
+            f32x2 bA, bB;  // column tile 0 / 1: (k = 4q + h, k = 4q + 2 + h)
+            auto read_b = [&](const float* pq, int u) {
+                bA = *reinterpret_cast<const f32x2*>(pq + u * 256);
+                bB = *reinterpret_cast<const f32x2*>(pq + u * 256 + 128);
             };
-            read_b(qb, bn);
+            read_b(plane + qb * 256, 0);
             int q0 = qb;
+            // steady state: every refill index q0 + RD + u and every B prefetch q0 + u + 1 is in range
+            for (; q0 + 2 * RD <= qe; q0 += RD) {
+                const float* xq = xr + 4 * (q0 + RD);
+                const float* pq = plane + q0 * 256;
+#pragma unroll
+                for (int u = 0; u < RD; ++u) {
+                    const float a0 = sel_half(ring[u][0], ring[u][1]);
+                    const float a1 = sel_half(ring[u][2], ring[u][3]);
+                    const f32x2 b0 = bA, b1 = bB;
+                    ring[u] = VEC ? *reinterpret_cast<const f32x4*>(xq + 4 * u) : load_x4(q0 + RD + u);
+                    read_b(pq, u + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[0], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1[0], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0[1], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[1], c1, 0, 0, 0);
+                }
+            }
+            // last full chunk(s): same body with clamped indices
             for (; q0 + RD <= qe; q0 += RD) {
 #pragma unroll
                 for (int u = 0; u < RD; ++u) {
                     const int qq = q0 + u;
                     const float a0 = sel_half(ring[u][0], ring[u][1]);
                     const float a1 = sel_half(ring[u][2], ring[u][3]);
-                    const float b0 = bn[0], b1 = bn[1], b2 = bn[2], b3 = bn[3];
+                    const f32x2 b0 = bA, b1 = bB;
                     ring[u] = load_x4((qq + RD < qlast) ? qq + RD : qlast);
-                    read_b((qq + 1 < qlast) ? qq + 1 : qlast, bn);
+                    read_b(plane + ((qq + 1 < qlast) ? qq + 1 : qlast) * 256, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c1, 0, 0, 0);
-                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[0], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1[0], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0[1], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[1], c1, 0, 0, 0);
                 }
             }
-            // tail (< RD groups of this k-block): plain loads; `bn` already holds group q0's fragments
+            // tail (< RD groups of this k-block): plain loads; bA/bB already hold group q0's operands
             for (int qq = q0; qq < qe; ++qq) {
                 const f32x4 xa = load_x4(qq);
                 const float a0 = sel_half(xa[0], xa[1]);
                 const float a1 = sel_half(xa[2], xa[3]);
-                const float b0 = bn[0], b1 = bn[1], b2 = bn[2], b3 = bn[3];
-                read_b((qq + 1 < qlast) ? qq + 1 : qlast, bn);
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c1, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, c1, 0, 0, 0);
+                const f32x2 b0 = bA, b1 = bB;
+                read_b(plane + ((qq + 1 < qlast) ? qq + 1 : qlast) * 256, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1[0], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0[1], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[1], c1, 0, 0, 0);
             }
             if (qb == 0) { tot0 = c0; tot1 = c1; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { tot0[r] = fadd(tot0[r], c0[r]); tot1[r] = fadd(tot1[r], c1[r]); }
+            }
+        }
+        const int cA = col0 + j, cB = col0 + 32 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (rr < left) {
+                float* o = out + (row0 + rr) * o_rs;
+                if (cA < d) __builtin_nontemporal_store(tot0[r], o + cA);
+                if (cB < d) __builtin_nontemporal_store(tot1[r], o + cB);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2/K4 v5  rotation GEMM, P-block stationary, x staged through LDS in full 128-byte lines.
+// Workgroup = 8 waves sharing one 64-column block of Pm in LDS; every wave owns 32-row tiles and a
+// private double-buffered LDS slab [32 rows][32 k].  A slab is fetched with 4 global_load_dwordx4 per
+// lane in which 8 consecutive lanes cover one row's 128 contiguous bytes (full lines, no reliance on
+// L1 to merge row-strided 16-byte pieces), written to LDS with the four k of a group in the order
+// (0, 2, 1, 3), and consumed as one ds_read_b64 per group: lane (row j, half h) gets k = 4q + h and
+// k = 4q + 2 + h at once -- no lane-half selects, no barriers in the loop (slabs are wave-private).
+// Per 4 MFMAs: 1 ds_read_b64 (A) + 1 ds_read2st64_b64 (B of both column tiles) + 1/2 global load +
+// 1/2 ds_write_b128.  Requires 16-byte aligned rows and d % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void k_rotate_pblock5(const float* __restrict__ x, int64_t n,
+                                                           int64_t x_rs, const float* __restrict__ Pm,
+                                                           int d, float* __restrict__ out, int64_t o_rs,
+                                                           int rows_per_wg, int ncb, int64_t rg_per_xcd)
+{
+    constexpr int XS = 36;                       // slab row stride in floats (144 B: 16-B aligned, 2-way banks)
+    extern __shared__ __attribute__((aligned(16))) float smem5[];
+    const int kpad = (d + 31) & ~31;             // whole 32-k slabs (zero padded)
+    float* pl = smem5;                           // [kpad / 4][64 cols][4]
+    float* xs_all = smem5 + (size_t)kpad * 64;   // [8 waves][2][32][XS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t q = b >> 3;
+    const int cb = (int)(q % ncb);
+    const int64_t rg_local = q / ncb;
+    const int64_t rg = rg_local * 8 + xcd;
+    const int col0 = cb * 64;
+
+    for (int idx = tid; idx < kpad * 16; idx += 512) {
+        const int k = idx >> 4, c4 = idx & 15, c = col0 + 4 * c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < d && c < d) v = *reinterpret_cast<const f32x4*>(Pm + (int64_t)k * d + c);
+        const int inner = ((k & 1) << 1) | ((k >> 1) & 1);
+        float* dst = pl + ((((k >> 2) << 6) + 4 * c4) << 2) + inner;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * e] = v[e];
+    }
+    __syncthreads();
+    if (rg_local >= rg_per_xcd) return;
+    const int64_t wg_row0 = rg * rows_per_wg;
+    if (wg_row0 >= n) return;
+    int64_t wg_row1 = wg_row0 + rows_per_wg;
+    if (wg_row1 > n) wg_row1 = n;
+
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                         0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float* xs = xs_all + (size_t)wave * 2 * 32 * XS;
+    const float* plane = pl + 4 * j + 2 * h;     // + q * 256 floats per group; + 128: second column tile
+    const int nslab = kpad / 32;
+    constexpr int SB = kKC / 32;                 // slabs per rule-2 block
+    const int lr = lane >> 3, lc = lane & 7;     // staging role: rows lr + 8 i, 16-byte piece lc
+
+    for (int64_t row0 = wg_row0 + 32 * wave; row0 < wg_row1; row0 += 256) {
+        const int left = (int)((n - row0 < 32) ? n - row0 : 32);
+        const float* rp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lr + 8 * i;
+            rp[i] = x + ((r < left) ? row0 + r : n - 1) * x_rs + 4 * lc;
+        }
+        f32x4 st[4];
+        auto fetch = [&](int slab) {             // 8 lanes x 16 B = one row's 128 contiguous bytes
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 32 * slab + 4 * lc;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < d) v = *reinterpret_cast<const f32x4*>(rp[i] + 32 * slab);
+                st[i] = v;
+            }
+        };
+        auto stash = [&](int buf) {              // (k0, k1, k2, k3) -> (k0, k2, k1, k3)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 w = {st[i][0], st[i][2], st[i][1], st[i][3]};
+                *reinterpret_cast<f32x4*>(xs + ((size_t)buf * 32 + lr + 8 * i) * XS + 4 * lc) = w;
+            }
+        };
+        fetch(0);
+        stash(0);
+        f32x16 tot0 = zero, tot1 = zero;
+        for (int sb = 0; sb < nslab; sb += SB) {
+            const int se = (sb + SB < nslab) ? sb + SB : nslab;
+            f32x16 c0 = zero, c1 = zero;
+            for (int slab = sb; slab < se; ++slab) {
+                const int buf = slab & 1;
+                const bool more = slab + 1 < nslab;
+                if (more) fetch(slab + 1);
+                const float* arow = xs + ((size_t)buf * 32 + j) * XS + 2 * h;
+                const float* pq = plane + slab * 8 * 256;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const f32x2 a = *reinterpret_cast<const f32x2*>(arow + 4 * u);
+                    const f32x2 b0 = *reinterpret_cast<const f32x2*>(pq + u * 256);
+                    const f32x2 b1 = *reinterpret_cast<const f32x2*>(pq + u * 256 + 128);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b0[0], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b1[0], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b0[1], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b1[1], c1, 0, 0, 0);
+                }
+                if (more) stash(buf ^ 1);
+            }
+            if (sb == 0) { tot0 = c0; tot1 = c1; }
             else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { tot0[r] = fadd(tot0[r], c0[r]); tot1[r] = fadd(tot1[r], c1[r]); }

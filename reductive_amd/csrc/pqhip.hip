@@ -208,6 +208,24 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
     const bool vec = (d % 4 == 0) && (x_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
     const int kpad = (d + 3) & ~3;
     const size_t pblock_bytes = (size_t)kpad * 64 * sizeof(float);
+    {
+        // v5: P block + wave-private x slabs in LDS, one 8-wave workgroup per CU
+        const int kpad32 = (d + 31) & ~31;
+        const size_t lds5 = ((size_t)kpad32 * 64 + (size_t)8 * 2 * 32 * 36) * sizeof(float);
+        static const bool use_v5 = getenv("PQHIP_DEBUG_NO_GEMM5") == nullptr;
+        if (use_v5 && vec && lds5 <= 160 * 1024) {
+            const int rows_per_wg = 4096;
+            const int ncb = (d + 63) / 64;
+            const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
+            const int64_t rg_per_xcd = (n_rg + 7) / 8;
+            const dim3 grid((unsigned)(rg_per_xcd * ncb * 8));
+            static bool attr5 = false;
+            if (!attr5) { HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr5 = true; }
+            hipLaunchKernelGGL(k_rotate_pblock5, grid, dim3(512), lds5, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, rg_per_xcd);
+            HIPCHK(hipGetLastError());
+            return PQHIP_OK;
+        }
+    }
     if (pblock_bytes <= 80 * 1024) {
         // P-block stationary kernel: 64 columns of Pm for all k live in LDS (2 workgroups per CU)
         const int rows_per_wg = 2048;
