@@ -389,33 +389,41 @@ __global__ __launch_bounds__(512, 2) void k_rotate_pblock5(const float* __restri
     constexpr int SB = kKC / 32;                 // slabs per rule-2 block
     const int lr = lane >> 3, lc = lane & 7;     // staging role: rows lr + 8 i, 16-byte piece lc
 
-    for (int64_t row0 = wg_row0 + 32 * wave; row0 < wg_row1; row0 += 256) {
+    const float* rp[4];
+    auto set_rows = [&](int64_t row0) {
         const int left = (int)((n - row0 < 32) ? n - row0 : 32);
-        const float* rp[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = lr + 8 * i;
             rp[i] = x + ((r < left) ? row0 + r : n - 1) * x_rs + 4 * lc;
         }
-        f32x4 st[4];
-        auto fetch = [&](int slab) {             // 8 lanes x 16 B = one row's 128 contiguous bytes
+    };
+    f32x4 st[4];
+    auto fetch = [&](int slab) {                 // 8 lanes x 16 B = one row's 128 contiguous bytes
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = 32 * slab + 4 * lc;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < d) v = *reinterpret_cast<const f32x4*>(rp[i] + 32 * slab);
-                st[i] = v;
-            }
-        };
-        auto stash = [&](int buf) {              // (k0, k1, k2, k3) -> (k0, k2, k1, k3)
+        for (int i = 0; i < 4; ++i) {
+            const int k = 32 * slab + 4 * lc;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < d) v = *reinterpret_cast<const f32x4*>(rp[i] + 32 * slab);
+            st[i] = v;
+        }
+    };
+    auto stash = [&](int buf) {                  // (k0, k1, k2, k3) -> (k0, k2, k1, k3)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 w = {st[i][0], st[i][2], st[i][1], st[i][3]};
-                *reinterpret_cast<f32x4*>(xs + ((size_t)buf * 32 + lr + 8 * i) * XS + 4 * lc) = w;
-            }
-        };
-        fetch(0);
-        stash(0);
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 w = {st[i][0], st[i][2], st[i][1], st[i][3]};
+            *reinterpret_cast<f32x4*>(xs + ((size_t)buf * 32 + lr + 8 * i) * XS + 4 * lc) = w;
+        }
+    };
+
+    int64_t row0 = wg_row0 + 32 * wave;
+    if (row0 >= wg_row1) return;
+    set_rows(row0);
+    fetch(0);
+    stash(0);
+    const int ob = (nslab - 1) & 1;              // buffer of the last slab: free once the k loop is done
+    for (; row0 < wg_row1; row0 += 256) {
+        const int left = (int)((n - row0 < 32) ? n - row0 : 32);
         f32x16 tot0 = zero, tot1 = zero;
         for (int sb = 0; sb < nslab; sb += SB) {
             const int se = (sb + SB < nslab) ? sb + SB : nslab;
@@ -444,16 +452,28 @@ __global__ __launch_bounds__(512, 2) void k_rotate_pblock5(const float* __restri
                 for (int r = 0; r < 16; ++r) { tot0[r] = fadd(tot0[r], c0[r]); tot1[r] = fadd(tot1[r], c1[r]); }
             }
         }
-        const int cA = col0 + j, cB = col0 + 32 + j;
+        // the next tile's first slab starts its trip from HBM before the stores of this one
+        const bool has_next = row0 + 256 < wg_row1;
+        if (has_next) { set_rows(row0 + 256); fetch(0); }
+        // epilogue: the 32 x 64 result goes through the free slab buffer so that every lane stores 16
+        // contiguous bytes (8 store instructions per tile instead of 64 dword stores: the dword tail
+        // was store-issue bound, ~7,500 cycles per tile)
+        float* os = xs + (size_t)ob * 32 * XS;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (rr < left) {
-                float* o = out + (row0 + rr) * o_rs;
-                if (cA < d) __builtin_nontemporal_store(tot0[r], o + cA);
-                if (cB < d) __builtin_nontemporal_store(tot1[r], o + cB);
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                os[((r & 3) + 8 * (r >> 2) + 4 * h) * XS + j] = ct ? tot1[r] : tot0[r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = lr + 8 * i;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(os + rr * XS + 4 * lc);
+                const int col = col0 + 32 * ct + 4 * lc;
+                if (rr < left && col < d)
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (row0 + rr) * o_rs + col));
             }
         }
+        if (has_next) stash(0);
     }
 }
 

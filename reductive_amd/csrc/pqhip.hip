@@ -213,7 +213,8 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         const int kpad32 = (d + 31) & ~31;
         const size_t lds5 = ((size_t)kpad32 * 64 + (size_t)8 * 2 * 32 * 36) * sizeof(float);
         static const bool use_v5 = getenv("PQHIP_DEBUG_NO_GEMM5") == nullptr;
-        if (use_v5 && vec && lds5 <= 160 * 1024) {
+        const bool out_vec = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
+        if (use_v5 && vec && out_vec && lds5 <= 160 * 1024) {
             const int rows_per_wg = 4096;
             const int ncb = (d + 63) / 64;
             const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
