@@ -220,8 +220,8 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
             const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
             const int64_t rg_per_xcd = (n_rg + 7) / 8;
             const dim3 grid((unsigned)(rg_per_xcd * ncb * 8));
-            static bool attr5 = false;
-            if (!attr5) { HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr5 = true; }
+            // (idempotent and cheap: set on every call rather than guarding a static flag across threads/devices)
+            HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL(k_rotate_pblock5, grid, dim3(512), lds5, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, rg_per_xcd);
             HIPCHK(hipGetLastError());
             return PQHIP_OK;
@@ -234,9 +234,8 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
         const int64_t rg_per_xcd = (n_rg + 7) / 8;
         const dim3 grid((unsigned)(rg_per_xcd * ncb * 8));
-        static bool attr_set[2] = {false, false};
         if (vec) {
-            if (!attr_set[1]) { HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr_set[1] = true; }
+            HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             if (getenv("PQHIP_DEBUG_OCC")) {
                 int nb = -1;
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_rotate_pblock<true>, 256, pblock_bytes);
@@ -244,7 +243,7 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
             }
             hipLaunchKernelGGL((k_rotate_pblock<true>), grid, dim3(256), pblock_bytes, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, rg_per_xcd);
         } else {
-            if (!attr_set[0]) { HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr_set[0] = true; }
+            HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             hipLaunchKernelGGL((k_rotate_pblock<false>), grid, dim3(256), pblock_bytes, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, rg_per_xcd);
         }
         HIPCHK(hipGetLastError());
@@ -508,7 +507,9 @@ int32_t pqhip_codebook_create(pqhip_ctx* ctx, const float* quantizers, int64_t M
     if (M <= 0 || K <= 0 || dsub <= 0) return PQHIP_ESHAPE;  // pq.rs:39-42 "without quantizers"
     if (M > 65535 || dsub > 65535 || K > (1ll << 31) - 1 || M * dsub > (1 << 24)) return PQHIP_EUNSUPPORTED;
 
-    std::unique_ptr<pqhip_codebook> cb(new pqhip_codebook());
+    // on any failure below the partially built handle (and its device memory) is destroyed
+    struct Guard { pqhip_codebook* p; ~Guard() { if (p) pqhip_codebook_destroy(p); } } guard{new pqhip_codebook()};
+    pqhip_codebook* cb = guard.p;
     cb->ctx = ctx;
     cb->M = M; cb->K = K; cb->dsub = dsub; cb->d = M * dsub;
     cb->has_proj = projection != nullptr;
@@ -573,7 +574,8 @@ int32_t pqhip_codebook_create(pqhip_ctx* ctx, const float* quantizers, int64_t M
         HIPCHK(hipEventRecord(cd.scratch_done, st));
     }
     cb->norms_ok = norms_ok;
-    *out = cb.release();
+    *out = cb;
+    guard.p = nullptr;
     return PQHIP_OK;
 }
 
