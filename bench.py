@@ -39,9 +39,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 WORKLOADS = {
-    "encode": "Pq::quantize_batch 10M x d=300 fp32, M=15, K=256 on 1 MI355X (BASELINE configs[1])",
-    "opq_encode": "Opq rotate+encode 10M x d=300, M=15, K=256 (BASELINE configs[2])",
-    "reconstruct": "Pq::reconstruct_batch u8 codes -> d=300 fp32 (BASELINE configs[3])",
+    "encode": "Pq::quantize_batch {rows} x d=300 fp32 per GPU, M=15, K=256 (BASELINE configs[1]: 10M on 1 MI355X)",
+    "opq_encode": "Opq rotate+encode {rows} x d=300 per GPU, M=15, K=256 (BASELINE configs[2])",
+    "reconstruct": "Pq::reconstruct_batch {rows} u8 codes -> d=300 fp32 per GPU (BASELINE configs[3])",
 }
 
 
@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 anchor kernel, 2 MFMA kernel")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for the barrier / max-reduction (gloo: rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise sharding/reduction/printing only (CPU, gloo); no GPU work")
     return ap.parse_args()
@@ -93,7 +97,7 @@ def main():
     use_gpu = not args.dry_run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.backend if use_gpu else "gloo", rank=rank, world_size=world)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     rows = args.rows
@@ -109,6 +113,8 @@ def main():
         import numpy as np
         import reductive_amd
         import synth
+        if args.single_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         reductive_amd.lib()                       # fails loudly if the HIP library is missing
@@ -160,7 +166,8 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if (use_gpu and world > 1) else "cpu")
+    tmax = torch.tensor([elapsed], dtype=torch.float64,
+                        device="cuda" if (use_gpu and world > 1 and args.backend == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -177,7 +184,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload] if (D, M) == (300, 15) else
+            "config": {"workload": WORKLOADS[args.workload].format(rows=rows) if (D, M) == (300, 15) else
                        "%s, non-headline shape d=%d M=%d" % (args.workload, D, M), "rows_per_gpu": rows,
                        "rows_total": total_rows, "d": D, "M": M, "K": K, "shards": shards,
                        "placement": "inputs and outputs resident in HBM; C ABI device entry point"},
