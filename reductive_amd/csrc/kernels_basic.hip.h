@@ -178,11 +178,11 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
         if (more) fetch_codes(blk + 1);  // in flight while this block is gathered and stored
         const int64_t row0 = blk * rows_per_block;
         const int rows = (n - row0 < rows_per_block) ? (int)(n - row0) : rows_per_block;
-        const int nchunks = rows * cpr;  // < 2^16 (host guarantees), so L / cpr == (L * inv) >> 16
+        const int nchunks = rows * cpr;  // < 2^16 (host guarantees), so L / cpr == umulhi(L, inv) exactly
         const IdxT* cc = cl + cur * ncode;
 #pragma unroll 4
         for (int L = threadIdx.x; L < nchunks; L += 256) {
-            const int row = (int)(((unsigned)L * inv_cpr) >> 16);
+            const int row = (cpr == 1) ? L : (int)__umulhi((unsigned)L, inv_cpr);
             const int c = L - row * cpr;
             const int me = tbl[c];
             const int m = me & 0xffff, e = me >> 16;
@@ -202,6 +202,29 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
         if (more) stash_codes(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+// Shapes outside k_reconstruct's per-block budgets (M > 4096 or a row of >= 2^16 chunks): one
+// thread per output element.  Same copy, no throughput claim.
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_reconstruct_any(const IdxT* __restrict__ codes, int64_t n,
+                                                         int64_t c_rs, float* __restrict__ out,
+                                                         int64_t o_rs, const float* __restrict__ cb,
+                                                         int M, int K, int dsub, int* __restrict__ err)
+{
+    const int64_t d = (int64_t)M * dsub;
+    const int64_t total = n * d;
+    bool bad = false;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / d;
+        const int64_t c = idx - row * d;
+        const int m = (int)(c / dsub), e = (int)(c - (int64_t)m * dsub);
+        uint64_t code = (uint64_t)codes[row * c_rs + m];
+        if (code >= (uint64_t)K) { bad = true; code = 0; }
+        out[row * o_rs + c] = cb[((int64_t)m * K + (int64_t)code) * dsub + e];
     }
     if (bad) atomicOr(err, 1);
 }

@@ -249,7 +249,15 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         HIPCHK(hipGetLastError());
         return PQHIP_OK;
     }
+    // any d: P slabs double-buffered through LDS (k-block loop restarts the chains every 256 k)
     const bool split = d > kKC;
+    constexpr int CT = 5;                      // 320 columns per workgroup
+    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((d + 2 * CT * 32 - 1) / (2 * CT * 32)));
+#define LAUNCH_ROT(SP, VE) \
+    hipLaunchKernelGGL((k_rotate_gemm<CT, SP, VE>), grid, dim3(256), 0, st, d_x, n, x_rs, Pm, d, d_out, o_rs)
+    if (split) { if (vec) LAUNCH_ROT(true, true); else LAUNCH_ROT(true, false); }
+    else { if (vec) LAUNCH_ROT(false, true); else LAUNCH_ROT(false, false); }
+#undef LAUNCH_ROT
     HIPCHK(hipGetLastError());
     return PQHIP_OK;
 }
@@ -280,19 +288,27 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     const bool vec = (cb->dsub % 4 == 0) && (o_rs % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
     const int cpr = vec ? d / 4 : d;
-    // rows per block: as many as keep rows*cpr < 2^16, the magic division exact and the block's
-    // codes within 16 elements per thread (<= 64)
+    // rows per block: as many as keep rows*cpr < 2^16 (so that L / cpr == umulhi(L, ceil(2^32 / cpr))
+    // exactly: the error term L * (inv * cpr - 2^32) stays below 2^32) and the block's codes within
+    // 16 elements per thread (<= 64)
     int rows_per_block = 64;
-    unsigned inv_cpr = 0;
-    for (;; rows_per_block /= 2) {
-        inv_cpr = (unsigned)((65536 + cpr - 1) / cpr);
-        bool exact = (int64_t)rows_per_block * cpr < 65536 && (int64_t)rows_per_block * cb->M <= 256 * 16;
-        for (int L = 0; exact && L < rows_per_block * cpr; ++L)
-            exact = (int)(((unsigned)L * inv_cpr) >> 16) == L / cpr;
-        if (exact || rows_per_block == 1) break;
+    while (rows_per_block > 1 &&
+           ((int64_t)rows_per_block * cpr >= 65536 || (int64_t)rows_per_block * cb->M > 256 * 16))
+        rows_per_block /= 2;
+    const unsigned inv_cpr = (cpr == 1) ? 0u : (unsigned)(((1ull << 32) + cpr - 1) / cpr);
+    if (cb->M > 256 * 16 || (int64_t)cpr >= 65536) {
+        const unsigned g = (unsigned)std::min<int64_t>((n * d + 255) / 256, 256 * 32);
+        if (code_bytes == 1)
+            hipLaunchKernelGGL((k_reconstruct_any<uint8_t>), dim3(g), dim3(256), 0, st, (const uint8_t*)d_codes, n, c_rs,
+                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, cd.err);
+        else if (code_bytes == 4)
+            hipLaunchKernelGGL((k_reconstruct_any<uint32_t>), dim3(g), dim3(256), 0, st, (const uint32_t*)d_codes, n, c_rs,
+                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, cd.err);
+        else
+            return PQHIP_EUNSUPPORTED;
+        HIPCHK(hipGetLastError());
+        return PQHIP_OK;
     }
-    if (cb->M > 256 * 16) return PQHIP_EUNSUPPORTED;
-    if ((int64_t)cpr >= 65536) return PQHIP_EUNSUPPORTED;
     const unsigned grid =
         (unsigned)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, 256 * 8);
     const size_t lds = (((size_t)cpr * sizeof(int) + 15) & ~(size_t)15) + 2 * (size_t)rows_per_block * cb->M * code_bytes;
