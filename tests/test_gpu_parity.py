@@ -489,3 +489,66 @@ def test_trained_codebook_and_opq_at_scale(ra):
     rec = pq.reconstruct_batch(want_o[:20_000])
     ref = orc.reconstruct_batch(q, want_o[:20_000], projection=P)
     assert np.abs(rec - ref).max() <= REL_TOL * np.abs(ref).max()
+
+
+# ---- randomized dispatch coverage ---------------------------------------------------------------
+def _fuzz_cases(count):
+    """Deterministic pseudo-random shapes (splitmix-style LCG, no numpy RNG stream dependence)."""
+    state = [0x9E3779B97F4A7C15]
+
+    def nxt(lo, hi):
+        state[0] = (state[0] * 6364136223846793005 + 1442695040888963407) & ((1 << 64) - 1)
+        return lo + (state[0] >> 33) % (hi - lo + 1)
+
+    ks = [1, 2, 5, 16, 31, 32, 33, 64, 100, 255, 256, 257, 300]
+    cases = []
+    for i in range(count):
+        M, dsub = nxt(1, 40), nxt(1, 36)
+        if i % 7 == 0:
+            dsub = 4 * nxt(1, 9)                      # keep the 16-byte paths well represented
+        K = ks[nxt(0, len(ks) - 1)]
+        n = nxt(1, 700)
+        opq = bool(nxt(0, 1)) and M * dsub <= 640
+        cases.append((i, M, K, dsub, n, opq, nxt(0, 4), nxt(0, 3), nxt(0, 3)))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(64), ids=lambda c: "i%d-M%d-K%d-ds%d-n%d-opq%d-p%d-o%d-c%d" % c)
+def test_randomized_shapes_host_and_device_entry_points(ra, case):
+    """Random (M, K, dsub, n, OPQ) through the host entry points, and -- for u8 codes -- through
+    the device entry points with padded row strides and base pointers off the 16-byte grid, so that
+    every vector/scalar-load dispatch decision of the library is exercised against the oracle."""
+    import torch
+    i, M, K, dsub, n, opq, pad, off, cpad = case
+    d = M * dsub
+    q = synth.normalish(1000 + i, (M, K, dsub))
+    x = synth.normalish(2000 + i, (n, d))
+    P = synth.orthonormal(3000 + i, d) if opq else None
+    dt = np.uint8 if K <= 256 else np.uint16
+    want = orc.quantize_batch(q, x, projection=P, dtype=dt)
+    ref = orc.reconstruct_batch(q, want, projection=P)
+    pq = _pq(ra, q, P)
+    assert pq.quantize_batch(x, dtype=dt).tobytes() == want.tobytes()
+    assert pq.reconstruct_batch(want).tobytes() == ref.tobytes()
+    if K > 256:
+        return
+    dev = torch.device("cuda:0")
+    xs = d + pad
+    xbuf = torch.zeros(off + n * xs, dtype=torch.float32, device=dev)
+    xv = xbuf[off:off + n * xs].view(n, xs)[:, :d]
+    xv.copy_(torch.from_numpy(x))
+    cbuf = torch.full((n, M + cpad), 0xEE, dtype=torch.uint8, device=dev)
+    cv = cbuf[:, :M]
+    pq.quantize_batch_device(xv, out=cv)
+    torch.cuda.synchronize()
+    assert cv.cpu().numpy().tobytes() == want.tobytes()
+    if cpad:
+        assert (cbuf[:, M:] == 0xEE).all().item()          # padding bytes untouched
+    obuf = torch.full((off + n * xs,), -7.0, dtype=torch.float32, device=dev)
+    ov = obuf[off:off + n * xs].view(n, xs)[:, :d]
+    pq.reconstruct_batch_device(cv, out=ov, check=True)
+    torch.cuda.synchronize()
+    assert ov.cpu().numpy().tobytes() == ref.tobytes()
+    if pad:
+        assert (obuf[off:off + n * xs].view(n, xs)[:, d:] == -7.0).all().item()
+    assert (obuf[:off] == -7.0).all().item()
