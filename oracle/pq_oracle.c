@@ -16,6 +16,8 @@
  *   src/kmeans.rs:111-126      cluster_assignment         (single-vector twin)
  *   src/linalg.rs:150-180      SquaredEuclideanDistance Ix2 x Ix2
  *   src/linalg.rs:118-148      SquaredEuclideanDistance Ix1 x Ix2
+ *   src/kmeans.rs:166-198, 308-360  update_centroids, kmeans_iteration, mean_squared_error
+ *                              ("next" row: the k-means step of PQ/OPQ training)
  *
  * PARITY STATUS.  The reference is Rust and cannot be compiled in this image
  * (no rustc/cargo), so this restatement is pinned by the reference's own
@@ -46,6 +48,9 @@
  *  (5) codes: `usize as u8` (primitives.rs:98-100); K <= 256 so no wrap here.
  *  (6) reconstruction: exact copy of codebook rows (primitives.rs:141-147);
  *      OPQ un-rotation r.dot(P^T) by rule (2).
+ *  (7) k-means step: centroid sums are sequential f32 adds in row order, counts are f32,
+ *      means by IEEE division; the loss is one sequential f32 fold over all elements.
+ *      (KATs: kmeans.rs:401-434, 506-520.)
  */
 #include <math.h>
 #include <pthread.h>
@@ -360,4 +365,69 @@ int pqo_quantize_vector(const float *cb, int64_t M, int64_t K, int64_t dsub, con
     return 0;
 }
 
-int pqo_abi_version(void) { return 1; }
+/* ---- "next" row: the k-means step of training -------------- */
+/* kmeans.rs:166-198 update_centroids.  centroids [K][dim] are zero-filled, every instance is
+ * added to its centroid IN ROW ORDER (`centroid += &instance`, one rounded f32 add per element),
+ * counts are f32 incremented by 1.0 (so they stick at 2^24), and non-empty centroids are divided
+ * by their count (`centroid /= &count`, IEEE division).  Empty clusters stay at zero. */
+void pqo_update_centroids(float *centroids, int64_t K, int64_t dim, const float *x, int64_t n,
+                          int64_t x_rs, int64_t x_cs, const int64_t *assign)
+{
+    float *counts = (float *)calloc((size_t)K, sizeof(float));
+    for (int64_t i = 0; i < K * dim; ++i) centroids[i] = 0.0f;
+    for (int64_t i = 0; i < n; ++i) {
+        float *c = centroids + assign[i] * dim;
+        for (int64_t e = 0; e < dim; ++e) c[e] = c[e] + x[i * x_rs + e * x_cs];
+        counts[assign[i]] = counts[assign[i]] + 1.0f;
+    }
+    for (int64_t k = 0; k < K; ++k)
+        if (counts[k] > 0.0f)
+            for (int64_t e = 0; e < dim; ++e) centroids[k * dim + e] = centroids[k * dim + e] / counts[k];
+    free(counts);
+}
+
+/* kmeans.rs:329-360 mean_squared_error: errors = centroids.select(assignments) - instances;
+ * sse = errors.into_iter().map(|v| v * v).sum()  -- ONE sequential f32 fold over all n*dim
+ * elements in row-major order; result sse / (n*dim as f32). */
+float pqo_mean_squared_error(const float *centroids, int64_t dim, const float *x, int64_t n,
+                             int64_t x_rs, int64_t x_cs, const int64_t *assign)
+{
+    float sse = 0.0f;
+    for (int64_t i = 0; i < n; ++i) {
+        const float *c = centroids + assign[i] * dim;
+        for (int64_t e = 0; e < dim; ++e) {
+            float err = c[e] - x[i * x_rs + e * x_cs];
+            float sq = err * err;
+            sse = sse + sq;
+        }
+    }
+    return sse / (float)(uint64_t)(n * dim);
+}
+
+/* kmeans.rs:308-327 kmeans_iteration (assignments by rule (1)-(4), update_centroids,
+ * mean_squared_error) run `n_iterations` times on every subquantizer's column block, i.e.
+ * kmeans_with_centroids(NIterationsCondition(n)) of pq.rs:176 for all m at once; n_iterations = 1
+ * is opq.rs:227-245 update_subquantizers.  cb [M][K][dsub] is updated in place; loss [M] (may be
+ * NULL) receives the last iteration's mean squared error of every subquantizer. */
+int pqo_kmeans_iterations(float *cb, int64_t M, int64_t K, int64_t dsub, const float *x, int64_t n,
+                          int64_t x_rs, int64_t x_cs, int n_iterations, float *loss, int n_threads)
+{
+    int64_t *codes = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n * M));
+    int64_t *col = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    for (int it = 0; it < n_iterations; ++it) {
+        int rc = pqo_quantize_batch(cb, M, K, dsub, NULL, x, n, x_rs, x_cs, codes, 8, M, 1, n_threads);
+        if (rc) { free(codes); free(col); return rc; }
+        for (int64_t m = 0; m < M; ++m) {
+            for (int64_t i = 0; i < n; ++i) col[i] = codes[i * M + m];
+            const float *xm = x + m * dsub * x_cs;
+            pqo_update_centroids(cb + m * K * dsub, K, dsub, xm, n, x_rs, x_cs, col);
+            if (loss && it == n_iterations - 1)
+                loss[m] = pqo_mean_squared_error(cb + m * K * dsub, dsub, xm, n, x_rs, x_cs, col);
+        }
+    }
+    free(codes);
+    free(col);
+    return 0;
+}
+
+int pqo_abi_version(void) { return 2; }

@@ -49,6 +49,14 @@ def lib():
                                             _i64, _i64, _fp, _i64, _i64]
         L.pqo_quantize_vector.restype = ctypes.c_int
         L.pqo_quantize_vector.argtypes = [_fp, _i64, _i64, _i64, _fp, _fp, ctypes.POINTER(_i64)]
+        L.pqo_update_centroids.restype = None
+        L.pqo_update_centroids.argtypes = [_fp, _i64, _i64, _fp, _i64, _i64, _i64,
+                                           ctypes.POINTER(_i64)]
+        L.pqo_mean_squared_error.restype = ctypes.c_float
+        L.pqo_mean_squared_error.argtypes = [_fp, _i64, _fp, _i64, _i64, _i64, ctypes.POINTER(_i64)]
+        L.pqo_kmeans_iterations.restype = ctypes.c_int
+        L.pqo_kmeans_iterations.argtypes = [_fp, _i64, _i64, _i64, _fp, _i64, _i64, _i64,
+                                            ctypes.c_int, _fp, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -148,3 +156,42 @@ def quantize_vector(quantizers, x, projection=None):
     lib().pqo_quantize_vector(_p(q), M, K, dsub, _p(P), _p(x),
                               out.ctypes.data_as(ctypes.POINTER(_i64)))
     return out
+
+
+# ---- "next" row: the k-means step of training (kmeans.rs:166-198, 308-360) ---------------------
+def update_centroids(centroids_shape, x, assignments):
+    """kmeans.rs:166-198 for instances along axis 0; returns the new [K, dim] centroids."""
+    K, dim = centroids_shape
+    x = np.asarray(x, dtype=np.float32)
+    a = np.ascontiguousarray(assignments, dtype=np.int64)
+    assert x.shape == (a.shape[0], dim), "The number of assignments should be equal to the number of instances."
+    out = np.empty((K, dim), np.float32)
+    rs, cs = _estrides(x) if x.size else (dim, 1)
+    lib().pqo_update_centroids(_p(out), K, dim, _p(x), x.shape[0], rs, cs,
+                               a.ctypes.data_as(ctypes.POINTER(_i64)))
+    return out
+
+
+def mean_squared_error(centroids, x, assignments):
+    """kmeans.rs:329-360 for instances along axis 0."""
+    c = _f32c(centroids)
+    x = np.asarray(x, dtype=np.float32)
+    a = np.ascontiguousarray(assignments, dtype=np.int64)
+    rs, cs = _estrides(x)
+    return np.float32(lib().pqo_mean_squared_error(_p(c), c.shape[1], _p(x), x.shape[0], rs, cs,
+                                                   a.ctypes.data_as(ctypes.POINTER(_i64))))
+
+
+def kmeans_iterations(quantizers, x, n_iterations=1, n_threads=1):
+    """`n_iterations` x kmeans_iteration (kmeans.rs:308-327) on every subquantizer's columns
+    (pq.rs:176 / opq.rs:227-245).  Returns (new quantizers [M,K,dsub], last loss [M])."""
+    q = _f32c(quantizers).copy()
+    M, K, dsub = q.shape
+    x = np.asarray(x, dtype=np.float32)
+    assert x.ndim == 2 and x.shape[1] == M * dsub, "Centroid and instance lengths differ."
+    rs, cs = _estrides(x)
+    loss = np.zeros(M, np.float32)
+    rc = lib().pqo_kmeans_iterations(_p(q), M, K, dsub, _p(x), x.shape[0], rs, cs, n_iterations,
+                                     _p(loss), n_threads)
+    assert rc == 0, rc
+    return q, loss

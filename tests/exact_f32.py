@@ -162,3 +162,38 @@ def reconstruct_batch(quantizers, codes, projection=None):
     if projection is not None:
         out = rotate(out, np.asarray(projection, np.float32).T)
     return out
+
+
+def fdiv(a, b):
+    if not (math.isfinite(a) and math.isfinite(b)) or b == 0:
+        with np.errstate(all="ignore"):
+            return float(np.float32(a) / np.float32(b))
+    return _round_f32(_F(a) / _F(b))
+
+
+def update_centroids(K, x, assignments):
+    """kmeans.rs:166-198: zero fill, sequential row-order adds, f32 counts, IEEE division."""
+    n, dim = x.shape
+    c = [[0.0] * dim for _ in range(K)]
+    cnt = [0.0] * K
+    for i in range(n):
+        a = int(assignments[i])
+        for e in range(dim):
+            c[a][e] = fadd(c[a][e], float(x[i, e]))
+        cnt[a] = fadd(cnt[a], 1.0)
+    for k in range(K):
+        if cnt[k] > 0:
+            c[k] = [fdiv(v, cnt[k]) for v in c[k]]
+    return np.array(c, np.float32)
+
+
+def mean_squared_error(centroids, x, assignments):
+    """kmeans.rs:329-360: one sequential fold of (c - x)^2 over all elements, / (n*dim)."""
+    n, dim = x.shape
+    sse = 0.0
+    for i in range(n):
+        a = int(assignments[i])
+        for e in range(dim):
+            err = fsub(float(centroids[a, e]), float(x[i, e]))
+            sse = fadd(sse, fmul(err, err))
+    return np.float32(fdiv(sse, float(np.float32(n * dim))))

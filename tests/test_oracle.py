@@ -191,3 +191,67 @@ def test_brute_force_f64_agrees_when_gap_is_clear():
     clear = (srt[..., 1] - srt[..., 0]) > 1e-3
     assert clear.mean() > 0.9
     assert (d.argmin(-1)[clear] == codes[clear]).all()
+
+
+# ---- "next" row: the k-means step of training (kmeans.rs:166-198, 308-360) ----------------------
+def test_kat_update_centroids(kats):
+    k = kats["update_centroids"]
+    x = np.array(k["instances"], np.float32)
+    got = orc.update_centroids(k["centroids_shape"], x, k["assignments"])
+    assert got.tolist() == k["expected"]
+    # instances along axis 1 (kmeans.rs:428-434): a transposed view of the same data
+    xt = np.asfortranarray(x)
+    assert orc.update_centroids(k["centroids_shape"], xt, k["assignments"]).tolist() == k["expected"]
+
+
+def test_kat_mean_squared_error(kats):
+    k = kats["mean_squared_error"]
+    x = np.array(k["instances"], np.float32)
+    want = np.float32(k["expected_num"]) / np.float32(k["expected_den"])
+    assert orc.mean_squared_error(k["centroids"], x, k["assignments"]) == want
+    assert orc.mean_squared_error(k["centroids"], np.asfortranarray(x), k["assignments"]) == want
+
+
+def test_update_centroids_and_loss_match_exact_model():
+    K, dim, n = 5, 3, 61
+    x = synth.normalish(501, (n, dim)) * np.float32(3.7)
+    a = synth.codes_u8(502, (n, 1), K)[:, 0].astype(np.int64)
+    a[a == 3] = 1                                    # cluster 3 stays empty -> zero centroid
+    c = orc.update_centroids((K, dim), x, a)
+    assert c.tobytes() == ex.update_centroids(K, x, a).tobytes()
+    assert (c[3] == 0).all()
+    assert orc.mean_squared_error(c, x, a) == ex.mean_squared_error(c, x, a)
+
+
+def test_kmeans_iterations_compose_the_three_steps():
+    """pqo_kmeans_iterations == cluster_assignments -> update_centroids -> mean_squared_error per
+    subquantizer (kmeans.rs:308-327), iterated (kmeans.rs:270-279)."""
+    M, K, dsub, n = 3, 8, 4, 300
+    q0 = synth.normalish(511, (M, K, dsub))
+    x = synth.normalish(512, (n, M * dsub))
+    q, loss = q0.copy(), np.zeros(M, np.float32)
+    for _ in range(3):
+        for m in range(M):
+            xs = x[:, m * dsub:(m + 1) * dsub]
+            a = orc.cluster_assignments(q[m], np.ascontiguousarray(xs))
+            q[m] = orc.update_centroids((K, dsub), xs, a)
+            loss[m] = orc.mean_squared_error(q[m], xs, a)
+    got_q, got_loss = orc.kmeans_iterations(q0, x, n_iterations=3)
+    assert got_q.tobytes() == q.tobytes() and got_loss.tobytes() == loss.tobytes()
+    got_q2, got_loss2 = orc.kmeans_iterations(q0, x, n_iterations=3, n_threads=4)
+    assert got_q2.tobytes() == q.tobytes() and got_loss2.tobytes() == loss.tobytes()
+    assert (got_loss[1:] != got_loss[:-1]).any()
+
+
+def test_kmeans_three_spheres(kats):
+    """kmeans.rs:436-480 with our own sample stream: 3 tight spheres, centroids initialised from
+    instances (one per sphere is what a lucky draw gives; the reference pins its seed for that)."""
+    k = kats["k_means_3"]
+    centers = np.array(k["centers"], np.float32)
+    pts = np.concatenate([c + np.float32(k["sigma"]) * synth.normalish(520 + i, (k["n_samples"], 2))
+                          for i, c in enumerate(centers)]).astype(np.float32)
+    init = pts[[3, 14, 30]][None]                    # RandomInstanceCentroids: k distinct instances
+    q, loss = orc.kmeans_iterations(init, pts, n_iterations=k["iterations"])
+    got = sorted(np.rint(q[0]).astype(int).tolist())
+    assert got == k["expected_rounded_sorted"]
+    assert loss[0] < 1e-3
