@@ -127,6 +127,37 @@ int32_t pqhip_cluster_assignments_f32(pqhip_ctx *ctx, const float *centroids, in
                                       int64_t x_row_stride, int64_t x_col_stride, void *out,
                                       int32_t out_bytes);
 
+/*
+ * The whole k-means step of PQ/OPQ training, for all M subquantizers at once: `n_iterations` times
+ * `kmeans_iteration` (src/kmeans.rs:308-327 = cluster_assignments :133-159, update_centroids
+ * :166-198, mean_squared_error :329-360) on every subquantizer's column block of x.  It replaces
+ *   - `sq_instances.kmeans_with_centroids(Axis(0), quantizer, NIterationsCondition(n_iterations))`
+ *     (src/pq/pq.rs:176; kmeans.rs:270-279) for every subquantizer of `train_pq_using`
+ *     (pq.rs:214-241), with the initial centroids of pq.rs:166-172 passed in;
+ *   - `Opq::update_subquantizers` (src/pq/opq.rs:227-245) with n_iterations = 1 and loss = NULL
+ *     (x = the rotated instances);
+ *   - a plain `kmeans_iteration` / `kmeans_with_centroids` with M = 1, dsub = dim.
+ * quantizers [M][K][dsub] (host, C order) holds the initial centroids and receives the updated
+ * ones; loss (host, [M], may be NULL) receives the LAST iteration's mean squared error of every
+ * subquantizer.  Results are bit-identical to the reference's sequential f32 arithmetic (sums in
+ * row order, f32 counts, IEEE division, one sequential fold for the loss); empty clusters become
+ * zero vectors as in kmeans.rs:180-197.  The instances stay resident on one device for all
+ * iterations (host entry point: the first device of the context).  Limits: K <= 16384,
+ * n_rows <= 2^31; shapes outside the MFMA encode kernels (K > 256 or dsub > 32) use the slow
+ * anchor kernel for the assignment step.  Both calls return synchronised.
+ */
+int32_t pqhip_kmeans_iterations_f32(pqhip_ctx *ctx, float *quantizers, int64_t n_subquantizers,
+                                    int64_t n_centroids, int64_t sub_dim, const float *x,
+                                    int64_t n_rows, int64_t x_row_stride, int64_t x_col_stride,
+                                    int32_t n_iterations, float *loss);
+
+/* same, instances already in HBM on `device_slot` (unit column stride) */
+int32_t pqhip_kmeans_iterations_f32_dev(pqhip_ctx *ctx, int32_t device_slot, float *quantizers,
+                                        int64_t n_subquantizers, int64_t n_centroids,
+                                        int64_t sub_dim, const float *d_x, int64_t n_rows,
+                                        int64_t x_row_stride, int32_t n_iterations, float *loss,
+                                        void *stream);
+
 /* ---- knobs used by the test-suite and the bench (not part of the reference surface) -------- */
 /* force a kernel variant for encode: 0 = auto, 1 = scalar VALU anchor kernel,
  * 2 = MFMA kernel with VALU argmin, 3 = MFMA + LDS-atomic argmin with register-resident codebook

@@ -88,6 +88,10 @@ def lib():
     L.pqhip_check_codes_dev.argtypes = [vp, i32, vp]
     L.pqhip_cluster_assignments_f32.restype = i32
     L.pqhip_cluster_assignments_f32.argtypes = [vp, fp, i64, i64, vp, i64, i64, i64, vp, i32]
+    L.pqhip_kmeans_iterations_f32.restype = i32
+    L.pqhip_kmeans_iterations_f32.argtypes = [vp, fp, i64, i64, i64, vp, i64, i64, i64, i32, fp]
+    L.pqhip_kmeans_iterations_f32_dev.restype = i32
+    L.pqhip_kmeans_iterations_f32_dev.argtypes = [vp, i32, fp, i64, i64, i64, vp, i64, i64, i32, fp, vp]
     L.pqhip_set_encode_variant.restype = i32
     L.pqhip_set_encode_variant.argtypes = [vp, i32]
     L.pqhip_last_encode_kernel.restype = ctypes.c_char_p
@@ -107,6 +111,6 @@ EXPORTS = [
     "pqhip_codebook_reconstructed_len", "pqhip_codebook_n_centroids",
     "pqhip_codebook_has_projection", "pqhip_quantize_batch_f32", "pqhip_reconstruct_batch_f32",
     "pqhip_quantize_batch_f32_dev", "pqhip_reconstruct_batch_f32_dev", "pqhip_check_codes_dev",
-    "pqhip_cluster_assignments_f32",
+    "pqhip_cluster_assignments_f32", "pqhip_kmeans_iterations_f32", "pqhip_kmeans_iterations_f32_dev",
     "pqhip_set_encode_variant", "pqhip_last_encode_kernel", "pqhip_selftest_mfma_chain",
 ]

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -22,6 +23,7 @@
 #include "kernels_basic.hip.h"
 #include "kernels_mfma.hip.h"
 #include "kernels_rotate.hip.h"
+#include "kernels_kmeans.hip.h"
 #include "encode_launch.h"
 
 using namespace pqhip;
@@ -259,6 +261,180 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
     else { if (vec) LAUNCH_ROT(false, true); else LAUNCH_ROT(false, false); }
 #undef LAUNCH_ROT
     HIPCHK(hipGetLastError());
+    return PQHIP_OK;
+}
+
+// (Re)derive everything the encode kernels need from the centroids in cd.cb: ||c||^2, the
+// finite/small-norm flag and the MFMA A-fragment image.  Synchronises `st` (4-byte flag readback).
+int32_t prepare_codebook_dev(pqhip_codebook* cb, int slot, hipStream_t st, bool* norms_ok)
+{
+    CodebookDev& cd = cb->dev[slot];
+    const int64_t M = cb->M, K = cb->K, dsub = cb->dsub;
+    HIPCHK(hipMemsetAsync(cd.err + 1, 0, sizeof(int), st));
+    {
+        const int total = (int)(M * cb->k_pad);
+        hipLaunchKernelGGL(k_centroid_norms, dim3((total + 255) / 256), dim3(256), 0, st, cd.cb,
+                           (int)M, (int)K, (int)dsub, cb->k_pad, cd.cc);
+        hipLaunchKernelGGL(k_check_norms, dim3((total + 255) / 256), dim3(256), 0, st, cd.cc,
+                           (int)M, (int)K, cb->k_pad, kBigNorm, cd.err + 1);
+    }
+    if (cb->T) {
+        const int S = cb->DP / 2;
+        const int64_t total = M * cb->T * S * 64;
+        hipLaunchKernelGGL(k_build_frags, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           cd.cb, (int)M, (int)K, (int)dsub, cb->T, S, cd.frags);
+    }
+    HIPCHK(hipGetLastError());
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, cd.err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *norms_ok = bad == 0;
+    return PQHIP_OK;
+}
+
+// only_slot < 0: replicate on every device of the context (Pq handles); otherwise build the
+// device copy on that slot alone (internal k-means handles).
+int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M, int64_t K,
+                             int64_t dsub, const float* projection, int only_slot,
+                             pqhip_codebook** out)
+{
+    if (!ctx || !out) return PQHIP_EINVAL;
+    *out = nullptr;
+    if (!quantizers) return PQHIP_EINVAL;
+    if (M <= 0 || K <= 0 || dsub <= 0) return PQHIP_ESHAPE;  // pq.rs:39-42 "without quantizers"
+    if (M > 65535 || dsub > 65535 || K > (1ll << 31) - 1 || M * dsub > (1 << 24)) return PQHIP_EUNSUPPORTED;
+    if (only_slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
+
+    // on any failure below the partially built handle (and its device memory) is destroyed
+    struct Guard { pqhip_codebook* p; ~Guard() { if (p) pqhip_codebook_destroy(p); } } guard{new pqhip_codebook()};
+    pqhip_codebook* cb = guard.p;
+    cb->ctx = ctx;
+    cb->M = M; cb->K = K; cb->dsub = dsub; cb->d = M * dsub;
+    cb->has_proj = projection != nullptr;
+    // MFMA geometry: K <= 256 padded to {1,2,4,8} tiles of 32; dsub <= 32 padded to a multiple
+    // of 4; resident A fragments must fit the register file (T * DP/2 <= 128).
+    int T = 0, DP = 0;
+    if (K <= 256 && dsub <= 32) {
+        const int tiles = (int)((K + 31) / 32);
+        T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
+        DP = (int)round_up(dsub, 4);
+        if (T * (DP / 2) > 128) { T = 0; DP = 0; }
+    }
+    cb->T = T; cb->DP = DP;
+    cb->k_pad = T ? T * 32 : (int)round_up(K, 32);
+    const int S = DP / 2;
+
+    std::vector<float> PT;
+    if (projection) {
+        PT.resize((size_t)cb->d * cb->d);
+        for (int64_t k = 0; k < cb->d; ++k)
+            for (int64_t c = 0; c < cb->d; ++c) PT[c * cb->d + k] = projection[k * cb->d + c];
+    }
+
+    cb->dev.resize(ctx->devs.size());
+    bool norms_ok = true;
+    for (size_t i = 0; i < ctx->devs.size(); ++i) {
+        if (only_slot >= 0 && (int)i != only_slot) continue;
+        CodebookDev& cd = cb->dev[i];
+        HIPCHK(hipSetDevice(ctx->devs[i]->ordinal));
+        hipStream_t st = ctx->devs[i]->stream[0];
+        const size_t cb_bytes = (size_t)(M * K * dsub) * sizeof(float);
+        HIPCHK(hipMalloc((void**)&cd.cb, cb_bytes));
+        HIPCHK(hipMemcpyAsync(cd.cb, quantizers, cb_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMalloc((void**)&cd.cc, (size_t)M * cb->k_pad * sizeof(float)));
+        HIPCHK(hipMalloc((void**)&cd.err, 2 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(cd.err, 0, 2 * sizeof(int), st));
+        HIPCHK(hipEventCreateWithFlags(&cd.scratch_done, hipEventDisableTiming));
+        if (T) HIPCHK(hipMalloc((void**)&cd.frags, (size_t)(M * T * S * 64) * sizeof(float)));
+        if (projection) {
+            const size_t pb = (size_t)cb->d * cb->d * sizeof(float);
+            HIPCHK(hipMalloc((void**)&cd.P, pb));
+            HIPCHK(hipMalloc((void**)&cd.PT, pb));
+            HIPCHK(hipMemcpyAsync(cd.P, projection, pb, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(cd.PT, PT.data(), pb, hipMemcpyHostToDevice, st));
+        }
+        bool ok = true;
+        PQCHK(prepare_codebook_dev(cb, (int)i, st, &ok));
+        if (!ok) norms_ok = false;
+        HIPCHK(hipEventRecord(cd.scratch_done, st));
+    }
+    cb->norms_ok = norms_ok;
+    *out = cb;
+    guard.p = nullptr;
+    return PQHIP_OK;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int32_t alloc(size_t bytes)
+    {
+        HIPCHK(hipMalloc(&p, bytes ? bytes : 1));
+        return PQHIP_OK;
+    }
+};
+
+// `n_iterations` x kmeans_iteration (kmeans.rs:308-327) on every subquantizer of `cb`, whose
+// device copy on `slot` is updated in place.  Work on one stream; returns synchronised.
+int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
+                       int n_iterations, float* h_loss, hipStream_t st)
+{
+    CodebookDev& cd = cb->dev[slot];
+    const int64_t M = cb->M, K = cb->K, dsub = cb->dsub;
+    if (n > (1ll << 31) || K > 16384) return PQHIP_EUNSUPPORTED;  // 32-bit row ids; K counters in LDS
+    if (n == 0) {
+        // no instances: every centroid is "empty" -> zero (kmeans.rs:180), loss 0/0
+        HIPCHK(hipMemsetAsync(cd.cb, 0, (size_t)(M * K * dsub) * sizeof(float), st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h_loss) for (int64_t m = 0; m < M; ++m) h_loss[m] = std::numeric_limits<float>::quiet_NaN();
+        return PQHIP_OK;
+    }
+    const int code_bytes = K <= 256 ? 1 : 4;
+    const int64_t rpb = std::max<int64_t>(4096, round_up((n + 255) / 256, 64));
+    const int nb = (int)((n + rpb - 1) / rpb);
+    DevBuf codes, counts, seg, perm, loss;
+    PQCHK(codes.alloc((size_t)n * M * code_bytes));
+    PQCHK(counts.alloc((size_t)M * nb * K * sizeof(unsigned)));
+    PQCHK(seg.alloc((size_t)M * (K + 1) * sizeof(unsigned)));
+    PQCHK(perm.alloc((size_t)M * n * sizeof(unsigned)));
+    PQCHK(loss.alloc((size_t)M * sizeof(float)));
+    const size_t lds_k = (size_t)K * sizeof(unsigned), lds_scan = (size_t)(K + 256) * sizeof(unsigned);
+    HIPCHK(hipFuncSetAttribute((const void*)k_km_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    const float len_f = (float)(uint64_t)(n * dsub);  // `instances.len().as_()` (kmeans.rs:359)
+
+    for (int it = 0; it < n_iterations; ++it) {
+        PQCHK(encode_plain_dev(cb, slot, d_x, n, x_rs, codes.p, code_bytes, M, st));
+        const dim3 gbm((unsigned)nb, (unsigned)M);
+#define KM_LAUNCH(IDX)                                                                                   \
+        hipLaunchKernelGGL((k_km_hist<IDX>), gbm, dim3(256), lds_k, st, (const IDX*)codes.p, n, M, (int)K, \
+                           (int)rpb, nb, (unsigned*)counts.p);                                           \
+        hipLaunchKernelGGL(k_km_scan, dim3((unsigned)M), dim3(256), lds_scan, st, (unsigned*)counts.p,   \
+                           (int)K, nb, (unsigned*)seg.p);                                                \
+        hipLaunchKernelGGL((k_km_scatter<IDX>), gbm, dim3(64), lds_k, st, (const IDX*)codes.p, n, M,     \
+                           (int)K, (int)rpb, nb, (const unsigned*)counts.p, (const unsigned*)seg.p,      \
+                           (unsigned*)perm.p)
+        if (code_bytes == 1) { KM_LAUNCH(uint8_t); } else { KM_LAUNCH(uint32_t); }
+#undef KM_LAUNCH
+        const int64_t lanes = M * K * dsub;
+        hipLaunchKernelGGL(k_km_segsum, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, d_x, x_rs, n,
+                           (const unsigned*)perm.p, (const unsigned*)seg.p, (int)M, (int)K, (int)dsub, cd.cb);
+        if (h_loss && it == n_iterations - 1) {
+            if (code_bytes == 1)
+                hipLaunchKernelGGL((k_km_loss<uint8_t>), dim3((unsigned)M), dim3(256), 0, st, d_x, x_rs, n,
+                                   (const uint8_t*)codes.p, M, cd.cb, (int)K, (int)dsub, len_f, (float*)loss.p);
+            else
+                hipLaunchKernelGGL((k_km_loss<uint32_t>), dim3((unsigned)M), dim3(256), 0, st, d_x, x_rs, n,
+                                   (const uint32_t*)codes.p, M, cd.cb, (int)K, (int)dsub, len_f, (float*)loss.p);
+        }
+        HIPCHK(hipGetLastError());
+        bool ok = true;
+        PQCHK(prepare_codebook_dev(cb, slot, st, &ok));  // also the per-iteration synchronisation point
+        cb->norms_ok = ok;
+    }
+    if (h_loss && n_iterations > 0) {
+        HIPCHK(hipMemcpyAsync(h_loss, loss.p, (size_t)M * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
     return PQHIP_OK;
 }
 
@@ -517,82 +693,7 @@ int32_t pqhip_ctx_n_devices(const pqhip_ctx* ctx) { return ctx ? (int32_t)ctx->d
 int32_t pqhip_codebook_create(pqhip_ctx* ctx, const float* quantizers, int64_t M, int64_t K,
                               int64_t dsub, const float* projection, pqhip_codebook** out)
 {
-    if (!ctx || !out) return PQHIP_EINVAL;
-    *out = nullptr;
-    if (!quantizers) return PQHIP_EINVAL;
-    if (M <= 0 || K <= 0 || dsub <= 0) return PQHIP_ESHAPE;  // pq.rs:39-42 "without quantizers"
-    if (M > 65535 || dsub > 65535 || K > (1ll << 31) - 1 || M * dsub > (1 << 24)) return PQHIP_EUNSUPPORTED;
-
-    // on any failure below the partially built handle (and its device memory) is destroyed
-    struct Guard { pqhip_codebook* p; ~Guard() { if (p) pqhip_codebook_destroy(p); } } guard{new pqhip_codebook()};
-    pqhip_codebook* cb = guard.p;
-    cb->ctx = ctx;
-    cb->M = M; cb->K = K; cb->dsub = dsub; cb->d = M * dsub;
-    cb->has_proj = projection != nullptr;
-    // MFMA geometry: K <= 256 padded to {1,2,4,8} tiles of 32; dsub <= 32 padded to a multiple
-    // of 4; resident A fragments must fit the register file (T * DP/2 <= 128).
-    int T = 0, DP = 0;
-    if (K <= 256 && dsub <= 32) {
-        const int tiles = (int)((K + 31) / 32);
-        T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
-        DP = (int)round_up(dsub, 4);
-        if (T * (DP / 2) > 128) { T = 0; DP = 0; }
-    }
-    cb->T = T; cb->DP = DP;
-    cb->k_pad = T ? T * 32 : (int)round_up(K, 32);
-    const int S = DP / 2;
-
-    std::vector<float> PT;
-    if (projection) {
-        PT.resize((size_t)cb->d * cb->d);
-        for (int64_t k = 0; k < cb->d; ++k)
-            for (int64_t c = 0; c < cb->d; ++c) PT[c * cb->d + k] = projection[k * cb->d + c];
-    }
-
-    cb->dev.resize(ctx->devs.size());
-    bool norms_ok = true;
-    for (size_t i = 0; i < ctx->devs.size(); ++i) {
-        CodebookDev& cd = cb->dev[i];
-        HIPCHK(hipSetDevice(ctx->devs[i]->ordinal));
-        hipStream_t st = ctx->devs[i]->stream[0];
-        const size_t cb_bytes = (size_t)(M * K * dsub) * sizeof(float);
-        HIPCHK(hipMalloc((void**)&cd.cb, cb_bytes));
-        HIPCHK(hipMemcpyAsync(cd.cb, quantizers, cb_bytes, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMalloc((void**)&cd.cc, (size_t)M * cb->k_pad * sizeof(float)));
-        HIPCHK(hipMalloc((void**)&cd.err, 2 * sizeof(int)));
-        HIPCHK(hipMemsetAsync(cd.err, 0, 2 * sizeof(int), st));
-        HIPCHK(hipEventCreateWithFlags(&cd.scratch_done, hipEventDisableTiming));
-        {
-            const int total = (int)(M * cb->k_pad);
-            hipLaunchKernelGGL(k_centroid_norms, dim3((total + 255) / 256), dim3(256), 0, st, cd.cb,
-                               (int)M, (int)K, (int)dsub, cb->k_pad, cd.cc);
-            hipLaunchKernelGGL(k_check_norms, dim3((total + 255) / 256), dim3(256), 0, st, cd.cc,
-                               (int)M, (int)K, cb->k_pad, kBigNorm, cd.err + 1);
-        }
-        if (T) {
-            const int64_t total = M * T * S * 64;
-            HIPCHK(hipMalloc((void**)&cd.frags, (size_t)total * sizeof(float)));
-            hipLaunchKernelGGL(k_build_frags, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                               cd.cb, (int)M, (int)K, (int)dsub, T, S, cd.frags);
-        }
-        if (projection) {
-            const size_t pb = (size_t)cb->d * cb->d * sizeof(float);
-            HIPCHK(hipMalloc((void**)&cd.P, pb));
-            HIPCHK(hipMalloc((void**)&cd.PT, pb));
-            HIPCHK(hipMemcpyAsync(cd.P, projection, pb, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(cd.PT, PT.data(), pb, hipMemcpyHostToDevice, st));
-        }
-        HIPCHK(hipGetLastError());
-        int bad = 0;
-        HIPCHK(hipMemcpyAsync(&bad, cd.err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (bad) norms_ok = false;
-        HIPCHK(hipEventRecord(cd.scratch_done, st));
-    }
-    cb->norms_ok = norms_ok;
-    *out = cb;
-    guard.p = nullptr;
-    return PQHIP_OK;
+    return codebook_create_impl(ctx, quantizers, M, K, dsub, projection, -1, out);
 }
 
 void pqhip_codebook_destroy(pqhip_codebook* cb)
@@ -806,6 +907,68 @@ int32_t pqhip_cluster_assignments_f32(pqhip_ctx* ctx, const float* centroids, in
     const int32_t rc = pqhip_quantize_batch_f32(cb, x, n_rows, x_rs, x_cs, out, out_bytes, 1, 1);
     pqhip_codebook_destroy(cb);
     return rc;
+}
+
+// ---- "next" row: the k-means step of training ---------------------------------------------------
+int32_t pqhip_kmeans_iterations_f32_dev(pqhip_ctx* ctx, int32_t slot, float* quantizers, int64_t M,
+                                        int64_t K, int64_t dsub, const float* d_x, int64_t n,
+                                        int64_t x_rs, int32_t n_iterations, float* loss, void* stream)
+{
+    if (!ctx || !quantizers || n < 0 || n_iterations < 0) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
+    if (n > 0 && (!d_x || x_rs < M * dsub)) return PQHIP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->devs[slot]->ordinal));
+    pqhip_codebook* cb = nullptr;
+    PQCHK(codebook_create_impl(ctx, quantizers, M, K, dsub, nullptr, slot, &cb));
+    struct G { pqhip_codebook* p; ~G() { pqhip_codebook_destroy(p); } } g{cb};
+    hipStream_t st = (hipStream_t)stream;
+    if (n_iterations > 0) PQCHK(kmeans_run_dev(cb, slot, d_x, n, x_rs, n_iterations, loss, st));
+    HIPCHK(hipMemcpy(quantizers, cb->dev[slot].cb, (size_t)(M * K * dsub) * sizeof(float), hipMemcpyDeviceToHost));
+    return PQHIP_OK;
+}
+
+int32_t pqhip_kmeans_iterations_f32(pqhip_ctx* ctx, float* quantizers, int64_t M, int64_t K, int64_t dsub,
+                                    const float* x, int64_t n, int64_t x_rs, int64_t x_cs,
+                                    int32_t n_iterations, float* loss)
+{
+    if (!ctx || !quantizers || n < 0 || n_iterations < 0) return PQHIP_EINVAL;
+    if (ctx->devs.empty()) return PQHIP_ENODEV;
+    if (M <= 0 || K <= 0 || dsub <= 0) return PQHIP_ESHAPE;
+    if (n > 0 && (!x || x_rs < 0 || x_cs < 0)) return PQHIP_EINVAL;
+    // the instances stay resident on the first device of the context for all iterations
+    const int slot = 0;
+    DeviceSlot& ds = *ctx->devs[slot];
+    const int64_t d = M * dsub;
+    DevBuf dx;
+    {
+        std::lock_guard<std::mutex> g(ds.mu);
+        HIPCHK(hipSetDevice(ds.ordinal));
+        PQCHK(dx.alloc((size_t)n * d * sizeof(float)));
+        const int64_t cap = std::min<int64_t>(kStageRows, std::max<int64_t>(n, 1));
+        for (int b = 0; b < 2; ++b) PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), 16));
+        const int nthreads = pack_threads(ctx);
+        int b = 0;
+        for (int64_t r0 = 0; r0 < n; r0 += cap, b ^= 1) {
+            const int64_t rows = std::min<int64_t>(cap, n - r0);
+            HIPCHK(hipStreamSynchronize(ds.stream[b]));
+            float* hin = (float*)ds.st[b].h_in;
+            parallel_rows(rows, nthreads, [&, r0, hin](int64_t ib, int64_t ie) {
+                if (x_cs == 1) {
+                    for (int64_t i = ib; i < ie; ++i)
+                        std::memcpy(hin + i * d, x + (r0 + i) * x_rs, (size_t)d * sizeof(float));
+                } else {
+                    for (int64_t i = ib; i < ie; ++i)
+                        for (int64_t k = 0; k < d; ++k) hin[i * d + k] = x[(r0 + i) * x_rs + k * x_cs];
+                }
+            });
+            HIPCHK(hipMemcpyAsync((float*)dx.p + r0 * d, hin, (size_t)rows * d * sizeof(float),
+                                  hipMemcpyHostToDevice, ds.stream[b]));
+        }
+        HIPCHK(hipStreamSynchronize(ds.stream[0]));
+        HIPCHK(hipStreamSynchronize(ds.stream[1]));
+    }
+    return pqhip_kmeans_iterations_f32_dev(ctx, slot, quantizers, M, K, dsub, (const float*)dx.p, n, d,
+                                           n_iterations, loss, (void*)ds.stream[0]);
 }
 
 int32_t pqhip_selftest_mfma_chain(pqhip_ctx* ctx, int32_t slot, int32_t k, int32_t n_trials,

@@ -23,6 +23,10 @@ class PanicError(AssertionError):
     """A Rust `panic!` / failed `assert!` of the reference surfaced as an exception."""
 
 
+class ReductiveError(ValueError):
+    """`ReductiveError` (src/error.rs:6-41): invalid training hyper-parameters."""
+
+
 _default_ctx = None
 _ctx_lock = threading.Lock()
 
@@ -110,6 +114,91 @@ def cluster_assignments(centroids, instances, dtype=np.uint64, ctx=None):
     if rc != _lib.OK:
         raise _lib.PqHipError(rc, "pqhip_cluster_assignments_f32")
     return out
+
+
+def kmeans_iterations(quantizers, instances, n_iterations=1, want_loss=True, ctx=None):
+    """`n_iterations` x `kmeans_iteration` (src/kmeans.rs:308-327) on every subquantizer's column
+    block, on the GPU: the body of `kmeans_with_centroids(.., NIterationsCondition(n))` at
+    pq.rs:176 for all subquantizers of `train_pq_using`, and of `Opq::update_subquantizers`
+    (opq.rs:227-245) when n_iterations == 1.  quantizers [M, K, dsub] are the initial centroids;
+    returns (updated quantizers, last mean squared error per subquantizer or None).
+    `instances` may be a numpy array [n, d] or a CUDA float32 torch tensor (kept in HBM)."""
+    q = np.array(quantizers, dtype=np.float32, order="C", copy=True)
+    if q.ndim == 2:
+        q = q[None]
+    if q.ndim != 3 or q.shape[1] == 0:
+        raise PanicError("Cannot cluster instances with zero centroids.")        # kmeans.rs:260-263
+    M, K, dsub = q.shape
+    ctx = ctx or default_ctx()
+    loss = np.zeros(M, np.float32) if want_loss else None
+    fp = ctypes.POINTER(ctypes.c_float)
+    lp = loss.ctypes.data_as(fp) if want_loss else None
+    L = _lib.lib()
+    if hasattr(instances, "is_cuda"):
+        import torch
+        x = instances
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+        if x.shape[1] != M * dsub:
+            raise PanicError("Centroid and instance lengths differ.")            # kmeans.rs:264-268
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        dev = x.device.index or 0
+        slot = dev if ctx.devices is None else ctx.devices.index(dev)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rs = x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1])
+        rc = L.pqhip_kmeans_iterations_f32_dev(ctx.handle, slot, q.ctypes.data_as(fp), M, K, dsub,
+                                               x.data_ptr(), x.shape[0], rs, n_iterations, lp,
+                                               ctypes.c_void_p(stream))
+    else:
+        x = np.asarray(instances, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != M * dsub:
+            raise PanicError("Centroid and instance lengths differ.")            # kmeans.rs:264-268
+        if any(s < 0 for s in x.strides) or any(s % 4 for s in x.strides):
+            x = np.ascontiguousarray(x)
+        rs, cs = _estrides(x) if x.size else (x.shape[1], 1)
+        rc = L.pqhip_kmeans_iterations_f32(ctx.handle, q.ctypes.data_as(fp), M, K, dsub, x.ctypes.data,
+                                           x.shape[0], rs, cs, n_iterations, lp)
+    if rc != _lib.OK:
+        raise _lib.PqHipError(rc, "pqhip_kmeans_iterations_f32")
+    return q, loss
+
+
+def train_pq(n_subquantizers, n_subquantizer_bits, n_iterations, n_attempts, instances, rng=None, ctx=None):
+    """`Pq::train_pq_using` (src/pq/pq.rs:214-241 -> train_subquantizer pq.rs:144-188) with the
+    k-means iterations on the GPU.  Initial centroids are K distinct random instances per
+    subquantizer (RandomInstanceCentroids, pq.rs:166-172); the draw uses numpy's generator, not the
+    reference's XorShift stream, so trained codebooks agree with the reference statistically, not
+    bit for bit.  The best of `n_attempts` (lowest final loss, first on ties) is kept per subquantizer."""
+    x = np.asarray(instances, dtype=np.float32)
+    n, d = x.shape
+    K = 1 << n_subquantizer_bits
+    # check_quantizer_invariants (pq.rs:63-100), same order, messages of error.rs:6-41
+    if n_subquantizers == 0 or n_subquantizers > d:
+        raise ReductiveError("The number of subquantizers must be between 1 and %d, was %d" % (d, n_subquantizers))
+    max_bits = int(np.trunc(np.log2(float(n)))) if n > 0 else 0
+    if n_subquantizer_bits == 0 or n_subquantizer_bits > max_bits:
+        raise ReductiveError("The number of subquantizers bits must be between 1 and %d" % max_bits)
+    if d % n_subquantizers != 0:
+        # (the reference's format string swaps the two numbers, error.rs:19-23; kept as is)
+        raise ReductiveError("The number of columns (%d) is not exactly dividable by the number of "
+                             "subquantizers (%d)" % (n_subquantizers, d))
+    if n_iterations == 0:
+        raise ReductiveError("The number of quantization iterations must be >= 1")
+    if n_attempts == 0:
+        raise ReductiveError("The number of quantization attempts per iteration must be >= 1")
+    rng = rng or np.random.default_rng(0)
+    M, dsub = n_subquantizers, d // n_subquantizers
+    best_q, best_loss = None, None
+    for _ in range(n_attempts):
+        init = np.stack([x[rng.choice(n, K, replace=False), m * dsub:(m + 1) * dsub] for m in range(M)])
+        q, loss = kmeans_iterations(init, x, n_iterations, want_loss=True, ctx=ctx)
+        if best_q is None:
+            best_q, best_loss = q, loss
+        else:
+            better = np.array([(not np.isnan(l)) and (np.isnan(b) or l < b) for l, b in zip(loss, best_loss)])
+            best_q[better] = q[better]
+            best_loss[better] = loss[better]
+    return Pq(None, best_q, ctx=ctx)
 
 
 class Pq:

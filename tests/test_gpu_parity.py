@@ -552,3 +552,130 @@ def test_randomized_shapes_host_and_device_entry_points(ra, case):
     if pad:
         assert (obuf[off:off + n * xs].view(n, xs)[:, d:] == -7.0).all().item()
     assert (obuf[:off] == -7.0).all().item()
+
+
+# ---- "next" row: the k-means step of training (kmeans.rs:166-198, 308-360) ----------------------
+KM_SHAPES = [  # n, M, K, dsub
+    (5000, 15, 256, 20),    # headline codebook shape
+    (3000, 4, 16, 8),
+    (777, 3, 5, 7),         # odd sub-dimension, K not a power of two
+    (4097, 1, 256, 32),     # plain k-means (M = 1)
+    (2000, 2, 300, 6),      # K > 256: 32-bit codes, anchor assignment kernel
+    (500, 2, 8, 40),        # dsub > 32: anchor assignment kernel
+    (64, 1, 64, 3),         # as many centroids as instances
+    (10, 2, 16, 4),         # fewer instances than centroids: most clusters stay empty
+    (1, 1, 2, 1),
+]
+
+
+def _km_inputs(n, M, K, dsub, seed):
+    x = synth.normalish(seed, (n, M * dsub))
+    pick = synth.codes_u8(seed + 1, (K, 4), 256).astype(np.int64)
+    rows = (pick[:, 0] * 65536 + pick[:, 1] * 256 + pick[:, 2]) % n
+    q0 = np.stack([x[rows, m * dsub:(m + 1) * dsub] for m in range(M)]).copy()
+    if K > n:
+        q0 += synth.normalish(seed + 2, q0.shape) * np.float32(0.1)
+    return q0, x
+
+
+@pytest.mark.parametrize("shape", KM_SHAPES)
+def test_kmeans_iterations_match_oracle(ra, shape):
+    n, M, K, dsub = shape
+    q0, x = _km_inputs(n, M, K, dsub, 700 + n)
+    for iters in (1, 3):
+        want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=iters)
+        got_q, got_loss = ra.kmeans_iterations(q0, x, n_iterations=iters)
+        assert got_q.tobytes() == want_q.tobytes(), iters
+        assert got_loss.tobytes() == want_loss.tobytes(), iters
+    # loss not asked for (opq.rs:227-245 discards it): same centroids
+    got_q2, none = ra.kmeans_iterations(q0, x, n_iterations=3, want_loss=False)
+    assert none is None and got_q2.tobytes() == want_q.tobytes()
+    assert q0.tobytes() == _km_inputs(n, M, K, dsub, 700 + n)[0].tobytes()   # inputs untouched
+
+
+def test_kmeans_kat_fixed_point_and_three_spheres(ra, kats):
+    # kmeans.rs:401-434: started from the expected centroids, the KAT's assignments are what
+    # cluster_assignments yields, and update_centroids must reproduce the expected means exactly
+    k = kats["update_centroids"]
+    x = np.array(k["instances"], np.float32)
+    c = np.array(k["expected"], np.float32)
+    assert orc.cluster_assignments(c, x).tolist() == k["assignments"]
+    q, loss = ra.kmeans_iterations(c[None], x, 1)
+    assert q[0].tolist() == k["expected"]
+    assert loss[0] == orc.mean_squared_error(c, x, k["assignments"])
+    q, _ = ra.kmeans_iterations(c[None], np.asfortranarray(x), 1)            # axis-1 layout
+    assert q[0].tolist() == k["expected"]
+    # kmeans.rs:436-480 (k_means_3) with our own sample stream
+    k = kats["k_means_3"]
+    centers = np.array(k["centers"], np.float32)
+    pts = np.concatenate([cc + np.float32(k["sigma"]) * synth.normalish(520 + i, (k["n_samples"], 2))
+                          for i, cc in enumerate(centers)]).astype(np.float32)
+    q, loss = ra.kmeans_iterations(pts[[3, 14, 30]][None], pts, k["iterations"])
+    assert sorted(np.rint(q[0]).astype(int).tolist()) == k["expected_rounded_sorted"]
+    want_q, want_loss = orc.kmeans_iterations(pts[[3, 14, 30]][None], pts, k["iterations"])
+    assert q.tobytes() == want_q.tobytes() and loss.tobytes() == want_loss.tobytes()
+
+
+def test_kmeans_special_values_and_empty_clusters(ra):
+    M, K, dsub, n = 2, 8, 4, 600
+    q0, x = _km_inputs(n, M, K, dsub, 810)
+    q0[0, 5] = 1e6                       # never chosen -> empty -> zero vector (kmeans.rs:192-196)
+    x[7, 1] = np.inf                     # poisons one centroid of m = 0 and its loss
+    x[9, 6] = np.nan
+    x[11] = -0.0
+    want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=2)
+    got_q, got_loss = ra.kmeans_iterations(q0, x, n_iterations=2)
+    assert got_q.tobytes() == want_q.tobytes()
+    assert got_loss.tobytes() == want_loss.tobytes()
+    assert np.isnan(want_loss).any()
+    one_q, _ = ra.kmeans_iterations(q0, x, n_iterations=1)
+    assert (one_q[0, 5] == 0).all()
+
+
+def test_kmeans_device_resident_strided_and_at_scale(ra):
+    import torch
+    n, M, K, dsub = 200_000, 15, 256, 20
+    d = M * dsub
+    q0, x = _km_inputs(n, M, K, dsub, 820)
+    want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=2, n_threads=16)
+    xbuf = torch.zeros((n, d + 4), dtype=torch.float32, device="cuda:0")
+    xv = xbuf[:, :d]
+    xv.copy_(torch.from_numpy(x))
+    got_q, got_loss = ra.kmeans_iterations(q0, xv, n_iterations=2)
+    assert got_q.tobytes() == want_q.tobytes()
+    assert got_loss.tobytes() == want_loss.tobytes()
+    # loss decreases from one Lloyd iteration to the next on this data
+    _, l1 = ra.kmeans_iterations(q0, xv, n_iterations=1)
+    assert (got_loss <= l1).all()
+
+
+def test_kmeans_f32_counts_saturate_like_the_reference(ra):
+    """kmeans.rs:184: counts are f32 incremented by one, so they stop at 2^24."""
+    n = (1 << 24) + 5
+    x = np.full((n, 1), 1.0, np.float32)
+    x[::2] = 3.0
+    q, loss = ra.kmeans_iterations(np.zeros((1, 1, 1), np.float32), x, 1)
+    want_q, want_loss = orc.kmeans_iterations(np.zeros((1, 1, 1), np.float32), x, 1)
+    assert q.tobytes() == want_q.tobytes() and loss.tobytes() == want_loss.tobytes()
+
+
+def test_train_pq_statistical_loss(ra, kats):
+    """pq.rs:431-440 (quantize_with_type): train on U[0,1) 256 x 20, M = 10, 7 bits... the
+    reference's bound on the mean Euclidean reconstruction loss must hold for GPU-trained codebooks."""
+    k = kats["statistical"]
+    x = synth.uniform01(830, (k["n"], k["d"]))
+    pq = ra.train_pq(k["n_subquantizers"], k["n_bits"], 10, 1, x, rng=np.random.default_rng(5))
+    codes = pq.quantize_batch(x)
+    rec = pq.reconstruct_batch(codes)
+    loss = np.sqrt(((x - rec) ** 2).sum(axis=1)).mean()
+    assert loss < k["loss_bound"], loss
+    with pytest.raises(ra.ReductiveError):
+        ra.train_pq(0, 4, 10, 1, x)
+    with pytest.raises(ra.ReductiveError):
+        ra.train_pq(10, 9, 10, 1, x)          # 2^9 > 256 instances
+    with pytest.raises(ra.ReductiveError):
+        ra.train_pq(3, 4, 10, 1, x)           # 20 % 3 != 0
+    with pytest.raises(ra.ReductiveError):
+        ra.train_pq(10, 4, 0, 1, x)
+    with pytest.raises(ra.ReductiveError):
+        ra.train_pq(10, 4, 10, 0, x)
