@@ -42,6 +42,7 @@ WORKLOADS = {
     "encode": "Pq::quantize_batch {rows} x d=300 fp32 per GPU, M=15, K=256 (BASELINE configs[1]: 10M on 1 MI355X)",
     "opq_encode": "Opq rotate+encode {rows} x d=300 per GPU, M=15, K=256 (BASELINE configs[2])",
     "reconstruct": "Pq::reconstruct_batch {rows} u8 codes -> d=300 fp32 per GPU (BASELINE configs[3])",
+    "kmeans": "kmeans_iteration on all 15 subquantizers (training step; SURVEY 8f rank 1), {rows} x d=300 per GPU, K=256",
 }
 
 
@@ -140,24 +141,50 @@ def main():
 
             def step():
                 pq.quantize_batch_device(src, out=dst)
-        for _ in range(args.warmup):
+        if args.workload == "kmeans":
+            # one step = one kmeans_iteration (assign + update) of all M subquantizers over the
+            # resident instances; the K timed steps are ONE library call with n_iterations = K,
+            # exactly how pq.rs:176 drives it (centroids carried from step to step)
+            from reductive_amd.pq import kmeans_iterations
+            # initial centroids = K distinct instances per subquantizer (RandomInstanceCentroids, pq.rs:166-172)
+            pick = torch.arange(K, device=dev) * (rows // K)
+            q0 = np.stack([src[(pick + 7 * m) % rows, m * DSUB:(m + 1) * DSUB].cpu().numpy() for m in range(M)])
+
+            def run_steps(k):
+                if k > 0:
+                    kmeans_iterations(q0, src, n_iterations=k, want_loss=False, ctx=ctx)
+            run_steps(args.warmup)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            kernel_ms = 1e3 * elapsed / args.steps
+            extra["encode_kernel"] = "k_encode_mfma_lds3<vec4>"
+            step = None
+        for _ in range(args.warmup if step else 0):
             step()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                for _ in range(args.steps)]
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for a, b in evs:
-            a.record()                            # same stream the kernels are launched on
-            step()
-            b.record()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-        extra["encode_kernel"] = pq.last_encode_kernel() if args.workload != "reconstruct" else "k_reconstruct"
+        if step:
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for a, b in evs:
+                a.record()                        # same stream the kernels are launched on
+                step()
+                b.record()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            extra["encode_kernel"] = pq.last_encode_kernel() if args.workload != "reconstruct" else "k_reconstruct"
     else:
         barrier()
         t0 = time.perf_counter()
@@ -178,7 +205,8 @@ def main():
         shape = "(d=%d, M=%d, K=%d)" % (D, M, K)
         names = {"encode": "vectors/sec PQ encode " + shape,
                  "opq_encode": "vectors/sec OPQ rotate+encode " + shape,
-                 "reconstruct": "vectors/sec PQ reconstruct " + shape}
+                 "reconstruct": "vectors/sec PQ reconstruct " + shape,
+                 "kmeans": "vectors/sec per k-means iteration, all subquantizers " + shape}
         rec = {
             "metric": names[args.workload], "value": value, "unit": "vectors/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,12 +232,13 @@ def main():
                 ach = flop * rows / sec / 1e12
                 rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                                   "kernel": extra["encode_kernel"] if args.workload == "encode" else "k_rotate_pblock5 + " + extra["encode_kernel"],
+                                   "kernel": {"encode": extra["encode_kernel"], "opq_encode": "k_rotate_pblock5 + " + extra["encode_kernel"],
+                                              "kmeans": extra["encode_kernel"] + " + k_km_{hist,scan,scatter,segsum} + codebook prep (whole iteration)"}[args.workload],
                                    "avg_launch_ms": kernel_ms, "algorithmic_flop_per_vector": flop,
                                    "algorithmic_bytes_per_vector": BYTES_PER_VEC,
                                    "hbm_gbs": BYTES_PER_VEC * rows / sec / 1e9,
                                    "hbm_frac": BYTES_PER_VEC * rows / sec / 1e9 / PEAK_HBM_GBS}
-            if world == 1 and not args.no_cpu_baseline and args.workload != "reconstruct":
+            if world == 1 and not args.no_cpu_baseline and args.workload in ("encode", "opq_encode"):
                 rec["cpu_baseline"] = cpu_baseline(args, q, P, src, dst, pq)
         print(json.dumps(rec), flush=True)
     if world > 1:

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_km_scatter(const IdxT* __restrict__ code
                                                    int64_t c_rs, int K, int rows_per_block, int nb,
                                                    const unsigned* __restrict__ base,
                                                    const unsigned* __restrict__ seg,
-                                                   unsigned* __restrict__ perm)
+                                                   unsigned* __restrict__ perm, int64_t n_pad)
 {
     extern __shared__ unsigned km_run[];  // [K] next free position of every cluster
     const int b = blockIdx.x, m = blockIdx.y, lane = threadIdx.x;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_km_scatter(const IdxT* __restrict__ code
     while ((1ll << nbits) < K) ++nbits;
     const int64_t row0 = (int64_t)b * rows_per_block;
     const int64_t rend = (row0 + rows_per_block < n) ? row0 + rows_per_block : n;
-    unsigned* pm = perm + (int64_t)m * n;
+    unsigned* pm = perm + (int64_t)m * n_pad;
     const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int64_t r0 = row0; r0 < rend; r0 += 64) {
         const int64_t r = r0 + lane;
@@ -122,10 +122,16 @@ __global__ __launch_bounds__(64) void k_km_scatter(const IdxT* __restrict__ code
 
 // U4  one lane per (m, k, e): sequential row-order sum of its cluster's instances, then the mean.
 // Counts are f32 in the reference (they stop growing at 2^24); division is IEEE.
+// The rows arrive in WINDOWS (consecutive row ranges, each with its own partition): the running
+// sums are carried from window to window in `acc`, the cluster sizes in tot_in -> tot_out, and the
+// last window divides.  (Windows exist so that this latency-bound walk can run beside the
+// MFMA-bound assignment kernel of the following rows on a second stream.)
 __global__ __launch_bounds__(256) void k_km_segsum(const float* __restrict__ x, int64_t x_rs,
-                                                   int64_t n, const unsigned* __restrict__ perm,
+                                                   int64_t x_ms, int64_t n_pad, const unsigned* __restrict__ perm,
                                                    const unsigned* __restrict__ seg, int M, int K,
-                                                   int dsub, float* __restrict__ cb)
+                                                   int dsub, float* __restrict__ acc,
+                                                   const unsigned* __restrict__ tot_in,
+                                                   unsigned* __restrict__ tot_out, int first, int last)
 {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (int64_t)M * K * dsub) return;
@@ -133,11 +139,13 @@ __global__ __launch_bounds__(256) void k_km_segsum(const float* __restrict__ x, 
     const int e = (int)(gid - (int64_t)mk * dsub);
     const int m = mk / K, k = mk - m * K;
     const unsigned beg = seg[(int64_t)m * (K + 1) + k], end = seg[(int64_t)m * (K + 1) + k + 1];
-    const unsigned* pm = perm + (int64_t)m * n;
-    const float* xc = x + (int64_t)m * dsub + e;
-    float s = 0.f;
+    const unsigned* pm = perm + (int64_t)m * n_pad;
+    const char* xc = reinterpret_cast<const char*>(x + (int64_t)m * x_ms + e);
+    const unsigned rsb = (unsigned)x_rs * 4u;  // row stride in bytes (< 2^32): one 32x32->64 mad per address
+    auto at = [&](unsigned row) { return *reinterpret_cast<const float*>(xc + (uint64_t)row * rsb); };
+    float s = first ? 0.f : acc[gid];
     unsigned i = beg;
-    constexpr int U = 8;
+    constexpr int U = 16;  // loads in flight per lane
     if (i + U <= end) {
         unsigned r[U];
 #pragma unroll
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void k_km_segsum(const float* __restrict__ x, 
         for (; i + 2 * U <= end; i += U) {
             float v[U];
 #pragma unroll
-            for (int j = 0; j < U; ++j) v[j] = xc[(int64_t)r[j] * x_rs];
+            for (int j = 0; j < U; ++j) v[j] = at(r[j]);
 #pragma unroll
             for (int j = 0; j < U; ++j) r[j] = pm[i + U + j];  // row ids of the next step
 #pragma unroll
@@ -153,15 +161,100 @@ __global__ __launch_bounds__(256) void k_km_segsum(const float* __restrict__ x, 
         }
         float v[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) v[j] = xc[(int64_t)r[j] * x_rs];
+        for (int j = 0; j < U; ++j) v[j] = at(r[j]);
 #pragma unroll
         for (int j = 0; j < U; ++j) s = fadd(s, v[j]);
         i += U;
     }
-    for (; i < end; ++i) s = fadd(s, xc[(int64_t)pm[i] * x_rs]);
-    const unsigned cnt = end - beg;
-    if (cnt) s = __fdiv_rn(s, (float)(cnt < (1u << 24) ? cnt : (1u << 24)));
-    cb[gid] = s;
+    for (; i < end; ++i) s = fadd(s, at(pm[i]));
+    const unsigned cnt = (first ? 0u : tot_in[mk]) + (end - beg);
+    if (last && cnt) s = __fdiv_rn(s, (float)(cnt < (1u << 24) ? cnt : (1u << 24)));
+    acc[gid] = s;
+    if (e == 0) tot_out[mk] = cnt;
+}
+
+// U4w  the same walk with one WAVE per cluster (m, k).  A wave cannot keep more than about 16
+// vector-memory instructions in flight, so what bounds the lane-per-chain form above is
+// latency / (rows per instruction): there every instruction fetches ONE row of each of its
+// clusters.  Here the 64 lanes fetch RPL = 64 / q consecutive rows of ONE cluster per instruction
+// (q lanes cover a sub-vector: dsub/4 lanes with 16-byte loads, or dsub lanes with 4-byte loads),
+// PF instructions deep; the rows are staged through a wave-private LDS slab and lanes 0..dsub-1
+// then add them to their dimension's chain in row order.  RPL * PF (96 for dsub = 20) rows per
+// memory round trip instead of 16, which also makes the walk insensitive to unbalanced clusters.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_km_segsum_w(const float* __restrict__ x, int64_t x_rs,
+                                                     int64_t x_ms, int64_t n_pad,
+                                                     const unsigned* __restrict__ perm,
+                                                     const unsigned* __restrict__ seg, int M, int K,
+                                                     int dsub, float* __restrict__ acc,
+                                                     const unsigned* __restrict__ tot_in,
+                                                     unsigned* __restrict__ tot_out, int first, int last)
+{
+    constexpr int PF = 8;
+    extern __shared__ __attribute__((aligned(16))) float km_slab[];  // [4 waves][PF][RPL][dsub]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int mk = blockIdx.x * 4 + wave;
+    if (mk >= M * K) return;  // (no workgroup barrier below)
+    const int m = mk / K, k = mk - m * K;
+    const int q = VEC ? (dsub >> 2) : dsub;  // lanes per row
+    const int RPL = 64 / q;                  // rows per load instruction
+    const int j = lane / q, c = lane - j * q;
+    const bool active = j < RPL;
+    float* buf = km_slab + (size_t)wave * PF * RPL * dsub;
+    const unsigned beg = seg[(int64_t)m * (K + 1) + k], end = seg[(int64_t)m * (K + 1) + k + 1];
+    const unsigned* pm = perm + (int64_t)m * n_pad;
+    const char* xc = reinterpret_cast<const char*>(x + (int64_t)m * x_ms + (VEC ? 4 * c : c));
+    const unsigned rsb = (unsigned)x_rs * 4u;  // row stride in bytes (< 2^32)
+    const int slot_off = j * dsub + (VEC ? 4 * c : c);  // this lane's place inside one step of the slab
+    float s = 0.f;
+    if (!first && lane < dsub) s = acc[(int64_t)mk * dsub + lane];
+
+    unsigned r[PF];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) {
+        const unsigned idx = beg + t * RPL + j;
+        r[t] = (active && idx < end) ? pm[idx] : 0u;
+    }
+    const unsigned per_iter = (unsigned)(PF * RPL);
+    for (unsigned i = beg; i < end; i += per_iter) {
+        f32x4 v4[PF];
+        float v1[PF];
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+            const unsigned idx = i + t * RPL + j;
+            if (active && idx < end) {
+                const char* p = xc + (uint64_t)r[t] * rsb;
+                if (VEC) v4[t] = *reinterpret_cast<const f32x4*>(p);
+                else v1[t] = *reinterpret_cast<const float*>(p);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {  // row ids of the next iteration
+            const unsigned idx = i + per_iter + t * RPL + j;
+            r[t] = (active && idx < end) ? pm[idx] : 0u;
+        }
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+            if (active) {
+                float* d = buf + t * RPL * dsub + slot_off;
+                if (VEC) *reinterpret_cast<f32x4*>(d) = v4[t];
+                else *d = v1[t];
+            }
+        }
+        const unsigned left = end - i;
+        const int cnt = left < per_iter ? (int)left : (int)per_iter;
+        if (lane < dsub) {
+            const float* col = buf + lane;
+#pragma unroll 8
+            for (int jj = 0; jj < cnt; ++jj) s = fadd(s, col[jj * dsub]);
+        }
+    }
+    const unsigned cntk = (first ? 0u : tot_in[mk]) + (end - beg);
+    if (lane < dsub) {
+        if (last && cntk) s = __fdiv_rn(s, (float)(cntk < (1u << 24) ? cntk : (1u << 24)));
+        acc[(int64_t)mk * dsub + lane] = s;
+    }
+    if (lane == 0) tot_out[mk] = cntk;
 }
 
 // U5  mean_squared_error: ONE sequential f32 fold over all n*dsub squared errors of a

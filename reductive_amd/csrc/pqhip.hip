@@ -382,6 +382,7 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
     CodebookDev& cd = cb->dev[slot];
     const int64_t M = cb->M, K = cb->K, dsub = cb->dsub;
     if (n > (1ll << 31) || K > 16384) return PQHIP_EUNSUPPORTED;  // 32-bit row ids; K counters in LDS
+    if (x_rs >= (1ll << 30)) return PQHIP_EUNSUPPORTED;           // 32-bit byte stride in the update walk
     if (n == 0) {
         // no instances: every centroid is "empty" -> zero (kmeans.rs:180), loss 0/0
         HIPCHK(hipMemsetAsync(cd.cb, 0, (size_t)(M * K * dsub) * sizeof(float), st));
@@ -390,34 +391,106 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
         return PQHIP_OK;
     }
     const int code_bytes = K <= 256 ? 1 : 4;
-    const int64_t rpb = std::max<int64_t>(4096, round_up((n + 255) / 256, 64));
-    const int nb = (int)((n + rpb - 1) / rpb);
-    DevBuf codes, counts, seg, perm, loss;
+    // Row windows: window w is assigned on `st`, and partitioned + summed on a second stream while
+    // the MFMA-bound assignment of window w+1 runs (the update walk is memory-latency bound, the
+    // two overlap well).  The chains carry over from window to window, so the order of the adds
+    // is still the row order.
+    const char* win_env = getenv("PQHIP_DEBUG_KM_WINROWS");  // (read per call: the tests shrink it to exercise many windows)
+    const int64_t win_rows_target = win_env ? std::max<int64_t>(1, atoll(win_env)) : (int64_t)(512 << 10);
+    const int64_t wrows = std::min<int64_t>(n, round_up(std::max<int64_t>(win_rows_target, (n + 31) / 32), 64));
+    const int nwin = (int)((n + wrows - 1) / wrows);
+    const int64_t rpb = std::max<int64_t>(4096, round_up((wrows + 255) / 256, 64));
+    const int nb_max = (int)((wrows + rpb - 1) / rpb);
+    const int64_t w_pad = round_up(wrows, 4);  // 16-byte aligned row-id groups for every subquantizer
+    DevBuf codes, counts, seg, perm, loss, acc, tot;
     PQCHK(codes.alloc((size_t)n * M * code_bytes));
-    PQCHK(counts.alloc((size_t)M * nb * K * sizeof(unsigned)));
+    PQCHK(counts.alloc((size_t)M * nb_max * K * sizeof(unsigned)));
     PQCHK(seg.alloc((size_t)M * (K + 1) * sizeof(unsigned)));
-    PQCHK(perm.alloc((size_t)M * n * sizeof(unsigned)));
+    PQCHK(perm.alloc((size_t)M * w_pad * sizeof(unsigned)));
     PQCHK(loss.alloc((size_t)M * sizeof(float)));
+    PQCHK(acc.alloc((size_t)(M * K * dsub) * sizeof(float)));
+    PQCHK(tot.alloc((size_t)2 * M * K * sizeof(unsigned)));
     const size_t lds_k = (size_t)K * sizeof(unsigned), lds_scan = (size_t)(K + 256) * sizeof(unsigned);
     HIPCHK(hipFuncSetAttribute((const void*)k_km_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     const float len_f = (float)(uint64_t)(n * dsub);  // `instances.len().as_()` (kmeans.rs:359)
+    const int64_t lanes = M * K * dsub;
+
+    const float* gx = d_x;  // what the update walk reads: the row-major instances themselves
+    const int64_t g_rs = x_rs, g_ms = dsub;
+    const bool vec4 = (dsub % 4 == 0) && (g_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(gx) & 15) == 0);
+
+    struct Aux {
+        hipStream_t s = nullptr;
+        std::vector<hipEvent_t> ev;
+        hipEvent_t done = nullptr;
+        ~Aux()
+        {
+            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+            if (done) (void)hipEventDestroy(done);
+            if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        }
+    } aux;
+    {
+        // highest priority: its short, latency-bound kernels must not queue behind the long
+        // assignment workgroups of the other stream
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&aux.s, hipStreamNonBlocking, greatest));
+    }
+    aux.ev.assign((size_t)nwin, nullptr);
+    for (int w = 0; w < nwin; ++w) HIPCHK(hipEventCreateWithFlags(&aux.ev[w], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&aux.done, hipEventDisableTiming));
+    hipStream_t su = aux.s;
 
     for (int it = 0; it < n_iterations; ++it) {
-        PQCHK(encode_plain_dev(cb, slot, d_x, n, x_rs, codes.p, code_bytes, M, st));
-        const dim3 gbm((unsigned)nb, (unsigned)M);
+        for (int w = 0; w < nwin; ++w) {
+            const int64_t r0 = (int64_t)w * wrows, rows = std::min<int64_t>(wrows, n - r0);
+            const float* xw = d_x + r0 * x_rs;
+            char* cw = (char*)codes.p + r0 * M * code_bytes;
+            PQCHK(encode_plain_dev(cb, slot, xw, rows, x_rs, cw, code_bytes, M, st));
+            HIPCHK(hipEventRecord(aux.ev[w], st));
+            HIPCHK(hipStreamWaitEvent(su, aux.ev[w], 0));
+            const int nb = (int)((rows + rpb - 1) / rpb);
+            const dim3 gbm((unsigned)nb, (unsigned)M);
 #define KM_LAUNCH(IDX)                                                                                   \
-        hipLaunchKernelGGL((k_km_hist<IDX>), gbm, dim3(256), lds_k, st, (const IDX*)codes.p, n, M, (int)K, \
-                           (int)rpb, nb, (unsigned*)counts.p);                                           \
-        hipLaunchKernelGGL(k_km_scan, dim3((unsigned)M), dim3(256), lds_scan, st, (unsigned*)counts.p,   \
-                           (int)K, nb, (unsigned*)seg.p);                                                \
-        hipLaunchKernelGGL((k_km_scatter<IDX>), gbm, dim3(64), lds_k, st, (const IDX*)codes.p, n, M,     \
-                           (int)K, (int)rpb, nb, (const unsigned*)counts.p, (const unsigned*)seg.p,      \
-                           (unsigned*)perm.p)
-        if (code_bytes == 1) { KM_LAUNCH(uint8_t); } else { KM_LAUNCH(uint32_t); }
+            hipLaunchKernelGGL((k_km_hist<IDX>), gbm, dim3(256), lds_k, su, (const IDX*)cw, rows, M, (int)K, \
+                               (int)rpb, nb, (unsigned*)counts.p);                                       \
+            hipLaunchKernelGGL(k_km_scan, dim3((unsigned)M), dim3(256), lds_scan, su, (unsigned*)counts.p, \
+                               (int)K, nb, (unsigned*)seg.p);                                            \
+            hipLaunchKernelGGL((k_km_scatter<IDX>), gbm, dim3(64), lds_k, su, (const IDX*)cw, rows, M,   \
+                               (int)K, (int)rpb, nb, (const unsigned*)counts.p, (const unsigned*)seg.p,  \
+                               (unsigned*)perm.p, w_pad)
+            if (code_bytes == 1) { KM_LAUNCH(uint8_t); } else { KM_LAUNCH(uint32_t); }
 #undef KM_LAUNCH
-        const int64_t lanes = M * K * dsub;
-        hipLaunchKernelGGL(k_km_segsum, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, d_x, x_rs, n,
-                           (const unsigned*)perm.p, (const unsigned*)seg.p, (int)M, (int)K, (int)dsub, cd.cb);
+            const unsigned* tin = (const unsigned*)tot.p + (size_t)(w & 1) * M * K;
+            unsigned* tout = (unsigned*)tot.p + (size_t)((w + 1) & 1) * M * K;
+            const int first = w == 0, last = w == nwin - 1;
+            const float* gw = gx + r0 * g_rs;
+            // one wave per cluster (rows of a sub-vector on q lanes); lane-per-chain form for very wide sub-vectors
+            const bool wave_form = !getenv("PQHIP_DEBUG_KM_LANEFORM") && dsub <= 64;  // one lane per dimension adds
+            if (wave_form) {
+                const int qq = vec4 ? (int)dsub / 4 : (int)dsub;
+                const size_t slab = (size_t)4 * 8 * (64 / qq) * dsub * sizeof(float);
+                const dim3 g((unsigned)((M * K + 3) / 4));
+                if (vec4)
+                    hipLaunchKernelGGL((k_km_segsum_w<true>), g, dim3(256), slab, su, gw, g_rs, g_ms, w_pad,
+                                       (const unsigned*)perm.p, (const unsigned*)seg.p, (int)M, (int)K, (int)dsub,
+                                       (float*)acc.p, tin, tout, first, last);
+                else
+                    hipLaunchKernelGGL((k_km_segsum_w<false>), g, dim3(256), slab, su, gw, g_rs, g_ms, w_pad,
+                                       (const unsigned*)perm.p, (const unsigned*)seg.p, (int)M, (int)K, (int)dsub,
+                                       (float*)acc.p, tin, tout, first, last);
+            } else {
+                hipLaunchKernelGGL(k_km_segsum, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, su, gw, g_rs, g_ms, w_pad,
+                                   (const unsigned*)perm.p, (const unsigned*)seg.p, (int)M, (int)K, (int)dsub,
+                                   (float*)acc.p, tin, tout, first, last);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        // the new centroids replace the old ones only after every window has been assigned
+        HIPCHK(hipEventRecord(aux.done, su));
+        HIPCHK(hipStreamWaitEvent(st, aux.done, 0));
+        HIPCHK(hipMemcpyAsync(cd.cb, acc.p, (size_t)lanes * sizeof(float), hipMemcpyDeviceToDevice, st));
         if (h_loss && it == n_iterations - 1) {
             if (code_bytes == 1)
                 hipLaunchKernelGGL((k_km_loss<uint8_t>), dim3((unsigned)M), dim3(256), 0, st, d_x, x_rs, n,

@@ -593,6 +593,24 @@ def test_kmeans_iterations_match_oracle(ra, shape):
     assert q0.tobytes() == _km_inputs(n, M, K, dsub, 700 + n)[0].tobytes()   # inputs untouched
 
 
+def test_kmeans_many_row_windows(ra, monkeypatch):
+    """The update runs window by window (overlapped with the assignment of the next window); with
+    the window shrunk to 64 rows the carried chains and counts cross dozens of windows."""
+    monkeypatch.setenv("PQHIP_DEBUG_KM_WINROWS", "64")
+    for (n, M, K, dsub) in [(5000, 15, 256, 20), (1999, 3, 5, 7), (130, 2, 300, 6), (700, 2, 4, 68), (900, 1, 3, 300)]:
+        q0, x = _km_inputs(n, M, K, dsub, 900 + n)
+        want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=2)
+        got_q, got_loss = ra.kmeans_iterations(q0, x, n_iterations=2)
+        assert got_q.tobytes() == want_q.tobytes()
+        assert got_loss.tobytes() == want_loss.tobytes()
+        # the lane-per-chain form of the walk (used for very wide sub-vectors) on the same inputs
+        monkeypatch.setenv("PQHIP_DEBUG_KM_LANEFORM", "1")
+        got_q, got_loss = ra.kmeans_iterations(q0, x, n_iterations=2)
+        monkeypatch.delenv("PQHIP_DEBUG_KM_LANEFORM")
+        assert got_q.tobytes() == want_q.tobytes()
+        assert got_loss.tobytes() == want_loss.tobytes()
+
+
 def test_kmeans_kat_fixed_point_and_three_spheres(ra, kats):
     # kmeans.rs:401-434: started from the expected centroids, the KAT's assignments are what
     # cluster_assignments yields, and update_centroids must reproduce the expected means exactly
