@@ -110,6 +110,7 @@ def main():
 
     kernel_ms = None
     extra = {}
+    q0 = None
     if use_gpu:
         import numpy as np
         import reductive_amd
@@ -240,6 +241,8 @@ def main():
                                    "hbm_frac": BYTES_PER_VEC * rows / sec / 1e9 / PEAK_HBM_GBS}
             if world == 1 and not args.no_cpu_baseline and args.workload in ("encode", "opq_encode"):
                 rec["cpu_baseline"] = cpu_baseline(args, q, P, src, dst, pq)
+            if world == 1 and not args.no_cpu_baseline and args.workload == "kmeans":
+                rec["cpu_baseline"] = cpu_baseline_kmeans(args, q0, src, ctx)
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
@@ -275,6 +278,26 @@ def cpu_baseline(args, q, P, src, dst, pq):
             "gpu_codes_identical_on_sample": same,
             "host_resident_api_value": n_h / t_h,
             "host_resident_api_identical": bool((c_h == c_mt[:n_h]).all())}
+
+
+def cpu_baseline_kmeans(args, q0, src, ctx):
+    """One kmeans_iteration of the oracle (assignment sharded over the host cores, update and loss
+    sequential as in the reference) on a bounded sample, and the GPU result on the same sample
+    checked bit for bit (centroids and losses)."""
+    from oracle import pq_oracle as orc
+    from reductive_amd.pq import kmeans_iterations
+    cores = os.cpu_count() or 1
+    n_s = min(args.cpu_rows // 2, src.shape[0])
+    x = src[:n_s].cpu().numpy()
+    t = time.perf_counter()
+    want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=1, n_threads=cores)
+    t_cpu = time.perf_counter() - t
+    got_q, got_loss = kmeans_iterations(q0, src[:n_s], n_iterations=1, want_loss=True, ctx=ctx)
+    return {"value": n_s / t_cpu, "unit": "vectors/s", "cores": cores, "kind": "port",
+            "sample": "one iteration over the first %d rows of the bench batch; oracle assignment on %d "
+                      "threads, update + loss sequential (%.1f s)" % (n_s, cores, t_cpu),
+            "gpu_centroids_identical_on_sample": bool(got_q.tobytes() == want_q.tobytes()),
+            "gpu_loss_identical_on_sample": bool(got_loss.tobytes() == want_loss.tobytes())}
 
 
 if __name__ == "__main__":

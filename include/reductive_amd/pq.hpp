@@ -232,4 +232,26 @@ private:
     pqhip_codebook* cb_ = nullptr;
 };
 
+// ---- "next" row: the k-means step of training ------------------------------------------------------
+// `n_iterations` x kmeans_iteration (src/kmeans.rs:308-327) on every subquantizer's column block:
+// the body of `kmeans_with_centroids(.., NIterationsCondition(n))` at pq.rs:176 for all
+// subquantizers, and of `Opq::update_subquantizers` (opq.rs:227-245) for n_iterations == 1.
+// `quantizers` ([M][K][dsub], C order) is updated in place; returns the last iteration's mean
+// squared error of every subquantizer (empty when want_loss is false).
+inline std::vector<float> kmeans_iterations(Context& ctx, std::vector<float>& quantizers, int64_t M, int64_t K,
+                                            int64_t dsub, View2<const float> instances, int n_iterations,
+                                            bool want_loss = true)
+{
+    if (K == 0 || quantizers.empty())
+        throw Panic("Cannot cluster instances with zero centroids.");                     // kmeans.rs:260-263
+    if ((int64_t)quantizers.size() != M * K * dsub || instances.cols != M * dsub)
+        throw Panic("Centroid and instance lengths differ.");                             // kmeans.rs:264-268
+    std::vector<float> loss(want_loss ? (size_t)M : 0);
+    const int32_t rc = pqhip_kmeans_iterations_f32(ctx.handle(), quantizers.data(), M, K, dsub, instances.ptr,
+                                                   instances.rows, instances.row_stride, instances.col_stride,
+                                                   n_iterations, want_loss ? loss.data() : nullptr);
+    if (rc != PQHIP_OK) throw HipError(rc, "pqhip_kmeans_iterations_f32");
+    return loss;
+}
+
 }  // namespace reductive_amd

@@ -16,7 +16,7 @@ use std::collections::HashMap;
 use std::os::raw::{c_char, c_void};
 use std::sync::{Mutex, Once};
 
-use ndarray::{ArrayBase, ArrayView2, ArrayView3, ArrayViewMut2, Data, Ix2};
+use ndarray::{ArrayViewMut3, ArrayBase, ArrayView2, ArrayView3, ArrayViewMut2, Data, Ix2};
 
 #[repr(C)]
 pub struct pqhip_ctx { _p: [u8; 0] }
@@ -43,6 +43,12 @@ extern "C" {
     pub fn pqhip_reconstruct_batch_f32(cb: *mut pqhip_codebook, codes: *const c_void, code_bytes: i32,
         n_rows: i64, codes_row_stride: i64, codes_col_stride: i64, out: *mut f32,
         out_row_stride: i64, out_col_stride: i64) -> i32;
+    pub fn pqhip_cluster_assignments_f32(ctx: *mut pqhip_ctx, centroids: *const f32, n_centroids: i64,
+        dim: i64, x: *const f32, n_rows: i64, x_row_stride: i64, x_col_stride: i64, out: *mut c_void,
+        out_bytes: i32) -> i32;
+    pub fn pqhip_kmeans_iterations_f32(ctx: *mut pqhip_ctx, quantizers: *mut f32, n_subquantizers: i64,
+        n_centroids: i64, sub_dim: i64, x: *const f32, n_rows: i64, x_row_stride: i64,
+        x_col_stride: i64, n_iterations: i32, loss: *mut f32) -> i32;
 }
 
 /// Batches smaller than this stay on the CPU path (a launch + PCIe round trip is pointless).
@@ -123,5 +129,33 @@ where A: 'static + Copy, I: 'static + Copy, S: Data<Elem = I>,
         std::mem::size_of::<I>() as i32, quantized.nrows() as i64, cs[0] as i64, cs[1] as i64,
         reconstructions.as_mut_ptr() as *mut f32, os[0] as i64, os[1] as i64) };
     if rc == PQHIP_ECODE_RANGE { panic!("ndarray: index out of bounds"); }   // primitives.rs:146
+    rc == PQHIP_OK
+}
+
+/// The k-means step of training for ALL subquantizers at once ("next" row of the hot path).
+/// Call sites in the reference:
+///  * `Pq::train_pq_using` (pq.rs:214-241): draw the initial centroids of every subquantizer with
+///    the per-subquantizer XorShift rngs exactly as `subquantizer_initial_centroids` does
+///    (pq.rs:105-123), stack them into one [M, K, dsub] array, then ONE call here with
+///    `n_iterations` replaces the M x `kmeans_with_centroids(.., NIterationsCondition(n))` of
+///    pq.rs:176; `losses` feeds the `min_by_key` over attempts (pq.rs:182-187).
+///  * `Opq::update_subquantizers` (opq.rs:227-245): n_iterations = 1, losses = None, x = rx.
+/// Returns false (caller keeps the CPU path) for A != f32, small inputs, negative strides, a
+/// missing device or any non-OK status.  Results are bit-identical to the sequential f32 arithmetic
+/// of kmeans.rs:166-198 and :329-360 under the crate's default (matrixmultiply) backend.
+pub fn try_kmeans_iterations<A, S>(mut quantizers: ArrayViewMut3<A>, instances: &ArrayBase<S, Ix2>,
+    n_iterations: usize, losses: Option<&mut [A]>) -> bool
+where A: 'static + Copy, S: Data<Elem = A>,
+{
+    if !same::<A, f32>() || instances.nrows() < MIN_GPU_ROWS || !quantizers.is_standard_layout() { return false; }
+    let h = match handles() { Some(h) => h.lock().unwrap(), None => return false };
+    let (m, k, dsub) = quantizers.dim();
+    if instances.ncols() != m * dsub { return false; }          // the caller's asserts fire on the CPU path
+    let xs = instances.strides();
+    if xs.iter().any(|&s| s < 0) { return false; }
+    let loss_ptr = match losses { Some(l) if l.len() == m => l.as_mut_ptr() as *mut f32, Some(_) => return false, None => std::ptr::null_mut() };
+    let rc = unsafe { pqhip_kmeans_iterations_f32(h.ctx, quantizers.as_mut_ptr() as *mut f32, m as i64, k as i64,
+        dsub as i64, instances.as_ptr() as *const f32, instances.nrows() as i64, xs[0] as i64, xs[1] as i64,
+        n_iterations as i32, loss_ptr) };
     rc == PQHIP_OK
 }

@@ -57,6 +57,17 @@ int main()
     auto rec = pq.reconstruct_batch<uint64_t>(View2<const uint64_t>(quant.data(), 4, 2));  // pq.rs:471-478
     for (int i = 0; i < 24; ++i) CHECK(rec[i] == recon[i]);
     CHECK(panics([&] { std::vector<uint8_t> bad = {0, 2}; pq.reconstruct_batch<uint8_t>(View2<const uint8_t>(bad.data(), 1, 2)); }));
+    {   // kmeans.rs:401-434 (correct_update_centroids): started from the expected means the KAT's
+        // assignments are the nearest-centroid assignments, so one iteration must reproduce them
+        Context ctx;
+        std::vector<float> c = {0.5f, 0.5f, 0, -1.5f, -1, 0, 0, 0, 1.5f};
+        const std::vector<float> want = c;
+        const std::vector<float> inst = {-1, -1, 0, 1, 1, 0, -2, -1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 2};
+        auto loss = kmeans_iterations(ctx, c, 1, 3, 3, View2<const float>(inst.data(), 6, 3), 1);
+        for (int i = 0; i < 9; ++i) CHECK(c[i] == want[i]);
+        CHECK(loss.size() == 1 && loss[0] == 2.0f / 18.0f);   // squared errors .25 .5 .25 .5 .25 .25 (exact), 18 elements
+        CHECK(panics([&] { std::vector<float> q(6); kmeans_iterations(ctx, q, 1, 2, 3, View2<const float>(inst.data(), 9, 2), 1); }));
+    }
     std::printf("all checks passed (GPU)\n");
     return 0;
 }
