@@ -27,10 +27,10 @@ FLOP_PER_VEC = 2 * K * D          # distance GEMM only: 153,600
 BYTES_PER_VEC = 4 * D + M         # algorithmic HBM bytes per vector: 1,215
 
 
-def set_shape(d, m):
+def set_shape(d, m, k=256):
     """non-headline shapes (e.g. BASELINE configs[4]: d=768, M=48) for exploration runs"""
-    global D, M, DSUB, FLOP_PER_VEC, BYTES_PER_VEC
-    D, M = d, m
+    global D, M, K, DSUB, FLOP_PER_VEC, BYTES_PER_VEC
+    D, M, K = d, m, k
     DSUB = D // M
     FLOP_PER_VEC = 2 * K * D
     BYTES_PER_VEC = 4 * D + M
@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="encode")
     ap.add_argument("--d", type=int, default=300)
     ap.add_argument("--m", type=int, default=15)
+    ap.add_argument("--k", type=int, default=256, help="centroids per subquantizer (<= 256 for u8 codes)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 anchor kernel, 2 MFMA kernel")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,8 +88,8 @@ def load_pmc_traffic(workload, rows):
 
 def main():
     args = parse()
-    if (args.d, args.m) != (300, 15):
-        set_shape(args.d, args.m)
+    if (args.d, args.m, args.k) != (300, 15, 256):
+        set_shape(args.d, args.m, args.k)
     import torch
     import torch.distributed as dist
 
@@ -213,8 +214,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload].format(rows=rows) if (D, M) == (300, 15) else
-                       "%s, non-headline shape d=%d M=%d" % (args.workload, D, M), "rows_per_gpu": rows,
+            "config": {"workload": WORKLOADS[args.workload].format(rows=rows) if (D, M, K) == (300, 15, 256) else
+                       "%s, non-headline shape d=%d M=%d K=%d" % (args.workload, D, M, K), "rows_per_gpu": rows,
                        "rows_total": total_rows, "d": D, "M": M, "K": K, "shards": shards,
                        "placement": "inputs and outputs resident in HBM; C ABI device entry point"},
         }

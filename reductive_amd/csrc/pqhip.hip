@@ -153,7 +153,10 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
         a.M = (int)cb->M; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
         // kernel kind: 0 VALU argmin, 1 LDS argmin (2 waves/SIMD), 2 LDS argmin + LDS A fragments
-        const int kind = cb->variant == 2 ? 0 : cb->variant == 3 ? 1 : 2;
+        // auto: for sub-vectors of <= 4 floats the per-distance work outweighs the MFMA chain and the
+        // LDS pipe (one atomic per 64 distances) becomes the bound: the VALU-argmin kernel is 10-15 % faster
+        const bool tiny = cb->variant == 0 && cb->DP <= 4 && code_bytes == 1;
+        const int kind = (cb->variant == 2 || tiny) ? 0 : cb->variant == 3 ? 1 : 2;
         dim3 grid;
         if (kind == 2) {
             // one workgroup = one subquantizer x 4 row streams (one per wave)
