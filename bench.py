@@ -42,6 +42,7 @@ WORKLOADS = {
     "encode": "Pq::quantize_batch {rows} x d=300 fp32 per GPU, M=15, K=256 (BASELINE configs[1]: 10M on 1 MI355X)",
     "opq_encode": "Opq rotate+encode {rows} x d=300 per GPU, M=15, K=256 (BASELINE configs[2])",
     "reconstruct": "Pq::reconstruct_batch {rows} u8 codes -> d=300 fp32 per GPU (BASELINE configs[3])",
+    "lookup": "embedding lookup: {rows} random rows of a resident 10M x 15 u8 code matrix -> select + reconstruct + per-row rescale, d=300 fp32 (SURVEY 8f rank 2)",
     "kmeans": "kmeans_iteration on all 15 subquantizers (training step; SURVEY 8f rank 1), {rows} x d=300 per GPU, K=256",
 }
 
@@ -135,6 +136,15 @@ def main():
 
             def step():
                 pq.reconstruct_batch_device(src, out=dst)
+        elif args.workload == "lookup":
+            n_codes = 10_000_000
+            src = torch.randint(0, K, (n_codes, M), device=dev, dtype=torch.uint8, generator=g)
+            sel = torch.randint(0, n_codes, (rows,), device=dev, dtype=torch.int64, generator=g)
+            scl = torch.rand((n_codes,), device=dev, dtype=torch.float32, generator=g) + 0.5
+            dst = torch.empty((rows, D), device=dev, dtype=torch.float32)
+
+            def step():
+                pq.reconstruct_rows_device(src, sel, scales=scl, out=dst)
         else:
             src = torch.empty((rows, D), device=dev, dtype=torch.float32)
             for r0 in range(0, rows, 1 << 20):    # N(0,1) like benches/pq.rs:9, generated in HBM
@@ -186,7 +196,7 @@ def main():
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
             kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-            extra["encode_kernel"] = pq.last_encode_kernel() if args.workload != "reconstruct" else "k_reconstruct"
+            extra["encode_kernel"] = pq.last_encode_kernel() if args.workload not in ("reconstruct", "lookup") else "k_reconstruct"
     else:
         barrier()
         t0 = time.perf_counter()
@@ -208,6 +218,7 @@ def main():
         names = {"encode": "vectors/sec PQ encode " + shape,
                  "opq_encode": "vectors/sec OPQ rotate+encode " + shape,
                  "reconstruct": "vectors/sec PQ reconstruct " + shape,
+                 "lookup": "vectors/sec select+reconstruct+rescale lookup " + shape,
                  "kmeans": "vectors/sec per k-means iteration, all subquantizers " + shape}
         rec = {
             "metric": names[args.workload], "value": value, "unit": "vectors/s",
@@ -223,11 +234,14 @@ def main():
         if use_gpu:
             sec = kernel_ms * 1e-3
             traffic = load_pmc_traffic(args.workload, rows)
-            if args.workload == "reconstruct":
+            if args.workload in ("reconstruct", "lookup"):
+                if args.workload == "lookup":
+                    global BYTES_PER_VEC
+                    BYTES_PER_VEC = 4 * D + M + 8 + 4     # output row + code row + row index + scale
                 ach = BYTES_PER_VEC * rows / sec / 1e9
                 rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
-                                   "kernel": "k_reconstruct", "avg_launch_ms": kernel_ms,
+                                   "kernel": "k_reconstruct" + ("<.., SEL>" if args.workload == "lookup" else ""), "avg_launch_ms": kernel_ms,
                                    "algorithmic_bytes_per_vector": BYTES_PER_VEC}
             else:
                 flop = FLOP_PER_VEC + (2 * D * D if args.workload == "opq_encode" else 0)

@@ -111,6 +111,24 @@ int32_t pqhip_reconstruct_batch_f32_dev(pqhip_codebook *cb, int32_t device_slot,
                                         int64_t codes_row_stride, float *d_out,
                                         int64_t out_row_stride, void *stream);
 
+/*
+ * "Next" row: the lookup path of a consumer that keeps a quantized
+ * matrix resident (finalfusion's quantized embedding storage is the out-of-tree example): row
+ * select, `Reconstruct::reconstruct_batch` (src/pq/traits.rs:109-117 -> src/pq/pq.rs:309-327) of the
+ * selected code rows, and an optional per-row rescale, fused into one pass over HBM:
+ *     out[i][:] = reconstruct(codes[rows[i]][:]) * scales[rows[i]]        (scales == NULL: no rescale)
+ * d_codes [n_codes][M] (1- or 4-byte codes, row stride in elements), d_rows [n] int64 and d_scales
+ * [n_codes] f32 live in HBM; out [n][d].  With a projection the un-rotation (pq.rs:323-326) runs
+ * before the rescale.  A row index outside [0, n_codes) is ndarray's `select` panic: it raises the
+ * same asynchronous flag as a code >= K (query with pqhip_check_codes_dev -> PQHIP_ECODE_RANGE).
+ * The multiply is one rounded f32 multiply per element, so results equal
+ * `reconstruct_batch(codes.select(Axis(0), rows)) * scales.select(rows)` bit for bit.
+ */
+int32_t pqhip_reconstruct_rows_f32_dev(pqhip_codebook *cb, int32_t device_slot, const void *d_codes,
+                                       int32_t code_bytes, int64_t n_codes, int64_t codes_row_stride,
+                                       const int64_t *d_rows, int64_t n_rows, const float *d_scales,
+                                       float *d_out, int64_t out_row_stride, void *stream);
+
 /* Reconstruct's range check is asynchronous on the device path: returns PQHIP_ECODE_RANGE if any
  * device call since the last query saw a code >= K (synchronises `stream`). */
 int32_t pqhip_check_codes_dev(pqhip_codebook *cb, int32_t device_slot, void *stream);

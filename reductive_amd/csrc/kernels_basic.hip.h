@@ -114,12 +114,19 @@ __global__ void k_rotate_scalar(const float* __restrict__ x, int64_t n, int64_t 
 // table built once per workgroup; (row, chunk) advance incrementally (no per-element division).
 // A code >= K (reference: index_axis panic) raises *err and is clamped so no access is OOB.
 // ---------------------------------------------------------------------------------------------
-template <typename IdxT, int VEC>
+// SEL = true is the lookup form ("next" row): output row i is the
+// reconstruction of code row sel_rows[i] of a resident [n_codes][M] matrix, times
+// sel_scales[sel_rows[i]] when scales are given (one rounded f32 multiply per element); a row index
+// outside [0, n_codes) raises *err like an out-of-range code (ndarray `select` panics) and yields row 0.
+template <typename IdxT, int VEC, bool SEL = false>
 __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ codes, int64_t n,
                                                      int64_t c_rs, float* __restrict__ out,
                                                      int64_t o_rs, const float* __restrict__ cb,
                                                      int M, int K, int dsub, int rows_per_block,
-                                                     unsigned inv_cpr, int* __restrict__ err)
+                                                     unsigned inv_cpr, int* __restrict__ err,
+                                                     const int64_t* __restrict__ sel_rows = nullptr,
+                                                     int64_t n_codes = 0,
+                                                     const float* __restrict__ sel_scales = nullptr)
 {
     // LDS: chunk -> (m, e) table, then the codes of the current and of the next row block.
     // The codes are the only operand that comes from HBM with a dependent use (code -> gather ->
@@ -133,6 +140,9 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
     int* tbl = reinterpret_cast<int*>(smem);  // [cpr]: m | (e << 16)
     const int ncode = rows_per_block * M;
     IdxT* cl = reinterpret_cast<IdxT*>(smem + (((size_t)cpr * 4 + 15) & ~(size_t)15));  // [2][ncode]
+    // SEL: per-row scale of the current and of the next block, behind the codes
+    float* scl = reinterpret_cast<float*>(smem + (((size_t)cpr * 4 + 15) & ~(size_t)15) +
+                                          (((size_t)2 * ncode * sizeof(IdxT) + 15) & ~(size_t)15));  // [2][rows_per_block]
     for (int c = threadIdx.x; c < cpr; c += blockDim.x) {
         const int f = c * VEC;
         tbl[c] = (f / dsub) | ((f % dsub) << 16);
@@ -146,6 +156,8 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
     if (blk_begin >= blk_end) return;
 
     IdxT pre[NE];
+    float pre_scale = 1.0f;
+    bool bad = false;
     auto fetch_codes = [&](int64_t blk) {  // element e of the block = (row e / M, m e % M)
         const int64_t row0 = blk * rows_per_block;
         const int rows = (n - row0 < rows_per_block) ? (int)(n - row0) : rows_per_block;
@@ -155,9 +167,19 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
             IdxT v = 0;
             if (e < rows * M) {
                 const int r = e / M, mm = e - r * M;
-                v = codes[(row0 + r) * c_rs + mm];
+                int64_t src = row0 + r;
+                if (SEL) {
+                    src = sel_rows[src];
+                    if (src < 0 || src >= n_codes) { bad = true; src = 0; }
+                }
+                v = codes[src * c_rs + mm];
             }
             pre[i] = v;
+        }
+        if (SEL && sel_scales && (int)threadIdx.x < rows) {
+            int64_t src = sel_rows[row0 + threadIdx.x];
+            if (src < 0 || src >= n_codes) src = 0;
+            pre_scale = sel_scales[src];
         }
     };
     auto stash_codes = [&](int buf) {
@@ -166,12 +188,12 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
             const int e = threadIdx.x + 256 * i;
             if (e < ncode) cl[buf * ncode + e] = pre[i];
         }
+        if (SEL && sel_scales && (int)threadIdx.x < rows_per_block) scl[buf * rows_per_block + threadIdx.x] = pre_scale;
     };
     fetch_codes(blk_begin);
     stash_codes(0);
     __syncthreads();
 
-    bool bad = false;
     int cur = 0;
     for (int64_t blk = blk_begin; blk < blk_end; ++blk) {
         const bool more = blk + 1 < blk_end;
@@ -190,13 +212,15 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
             if (code >= (uint64_t)K) { bad = true; code = 0; }
             const float* src = cb + ((int64_t)m * K + (int64_t)code) * dsub + e;
             float* dst = out + (row0 + row) * o_rs + (int64_t)c * VEC;
+            const float sc = (SEL && sel_scales) ? scl[cur * rows_per_block + row] : 1.0f;
             if (VEC == 4) {
                 // streaming store: keep the L2 for the codebook, not for the 1.2 KB/row output
-                __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(src),
-                                            reinterpret_cast<f32x4*>(dst));
+                f32x4 q = *reinterpret_cast<const f32x4*>(src);
+                if (SEL && sel_scales) { q[0] = fmul(q[0], sc); q[1] = fmul(q[1], sc); q[2] = fmul(q[2], sc); q[3] = fmul(q[3], sc); }
+                __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(dst));
             } else {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) dst[v] = src[v];
+                for (int v = 0; v < VEC; ++v) dst[v] = (SEL && sel_scales) ? fmul(src[v], sc) : src[v];
             }
         }
         if (more) stash_codes(cur ^ 1);
@@ -212,7 +236,10 @@ template <typename IdxT>
 __global__ __launch_bounds__(256) void k_reconstruct_any(const IdxT* __restrict__ codes, int64_t n,
                                                          int64_t c_rs, float* __restrict__ out,
                                                          int64_t o_rs, const float* __restrict__ cb,
-                                                         int M, int K, int dsub, int* __restrict__ err)
+                                                         int M, int K, int dsub, int* __restrict__ err,
+                                                         const int64_t* __restrict__ sel_rows,
+                                                         int64_t n_codes,
+                                                         const float* __restrict__ sel_scales)
 {
     const int64_t d = (int64_t)M * dsub;
     const int64_t total = n * d;
@@ -222,11 +249,34 @@ __global__ __launch_bounds__(256) void k_reconstruct_any(const IdxT* __restrict_
         const int64_t row = idx / d;
         const int64_t c = idx - row * d;
         const int m = (int)(c / dsub), e = (int)(c - (int64_t)m * dsub);
-        uint64_t code = (uint64_t)codes[row * c_rs + m];
+        int64_t src = row;
+        if (sel_rows) {
+            src = sel_rows[row];
+            if (src < 0 || src >= n_codes) { bad = true; src = 0; }
+        }
+        uint64_t code = (uint64_t)codes[src * c_rs + m];
         if (code >= (uint64_t)K) { bad = true; code = 0; }
-        out[row * o_rs + c] = cb[((int64_t)m * K + (int64_t)code) * dsub + e];
+        float v = cb[((int64_t)m * K + (int64_t)code) * dsub + e];
+        if (sel_rows && sel_scales) v = fmul(v, sel_scales[src]);
+        out[row * o_rs + c] = v;
     }
     if (bad) atomicOr(err, 1);
+}
+
+// out[row][0..d) *= scales[sel_rows[row]]  (lookup form with a projection: the scale follows the un-rotation)
+__global__ __launch_bounds__(256) void k_scale_rows(float* __restrict__ out, int64_t n, int d, int64_t o_rs,
+                                                    const int64_t* __restrict__ sel_rows, int64_t n_codes,
+                                                    const float* __restrict__ sel_scales)
+{
+    const int64_t total = n * d;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / d;
+        const int c = (int)(idx - row * d);
+        int64_t src = sel_rows[row];
+        if (src < 0 || src >= n_codes) src = 0;
+        out[row * o_rs + c] = fmul(out[row * o_rs + c], sel_scales[src]);
+    }
 }
 
 }  // namespace pqhip

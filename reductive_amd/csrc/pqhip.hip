@@ -532,7 +532,8 @@ int32_t ensure_scratch(pqhip_codebook* cb, int slot, int64_t rows)
 }
 
 int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes, int64_t n,
-                   int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st)
+                   int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st,
+                   const int64_t* sel_rows = nullptr, int64_t n_codes = 0, const float* sel_scales = nullptr)
 {
     if (n == 0) return PQHIP_OK;
     CodebookDev& cd = cb->dev[slot];
@@ -552,10 +553,10 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
         const unsigned g = (unsigned)std::min<int64_t>((n * d + 255) / 256, 256 * 32);
         if (code_bytes == 1)
             hipLaunchKernelGGL((k_reconstruct_any<uint8_t>), dim3(g), dim3(256), 0, st, (const uint8_t*)d_codes, n, c_rs,
-                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, cd.err);
+                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, cd.err, sel_rows, n_codes, sel_scales);
         else if (code_bytes == 4)
             hipLaunchKernelGGL((k_reconstruct_any<uint32_t>), dim3(g), dim3(256), 0, st, (const uint32_t*)d_codes, n, c_rs,
-                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, cd.err);
+                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, cd.err, sel_rows, n_codes, sel_scales);
         else
             return PQHIP_EUNSUPPORTED;
         HIPCHK(hipGetLastError());
@@ -563,11 +564,22 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     }
     const unsigned grid =
         (unsigned)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, 256 * 8);
-    const size_t lds = (((size_t)cpr * sizeof(int) + 15) & ~(size_t)15) + 2 * (size_t)rows_per_block * cb->M * code_bytes;
+    const size_t lds = (((size_t)cpr * sizeof(int) + 15) & ~(size_t)15) +
+                       (((size_t)2 * rows_per_block * cb->M * code_bytes + 15) & ~(size_t)15) +
+                       (sel_rows ? (size_t)2 * rows_per_block * sizeof(float) : 0);
 #define LAUNCH_REC(IDX, V)                                                                        \
-    hipLaunchKernelGGL((k_reconstruct<IDX, V>), dim3(grid), dim3(256), lds, st,                   \
-                       (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K,  \
-                       (int)cb->dsub, rows_per_block, inv_cpr, cd.err)
+    do {                                                                                          \
+        if (sel_rows)                                                                             \
+            hipLaunchKernelGGL((k_reconstruct<IDX, V, true>), dim3(grid), dim3(256), lds, st,     \
+                               (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
+                               (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, cd.err,        \
+                               sel_rows, n_codes, sel_scales);                                    \
+        else                                                                                      \
+            hipLaunchKernelGGL((k_reconstruct<IDX, V, false>), dim3(grid), dim3(256), lds, st,    \
+                               (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
+                               (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, cd.err,        \
+                               (const int64_t*)nullptr, (int64_t)0, (const float*)nullptr);       \
+    } while (0)
     if (code_bytes == 1) { if (vec) LAUNCH_REC(uint8_t, 4); else LAUNCH_REC(uint8_t, 1); }
     else if (code_bytes == 4) { if (vec) LAUNCH_REC(uint32_t, 4); else LAUNCH_REC(uint32_t, 1); }
     else return PQHIP_EUNSUPPORTED;
@@ -595,20 +607,34 @@ int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_
     return PQHIP_OK;
 }
 
+// sel_rows != nullptr: lookup form -- output row i reconstructs code row sel_rows[i] (and is scaled
+// by sel_scales[sel_rows[i]] when given); d_codes is then the whole resident [n_codes][M] matrix.
 int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes,
-                             int64_t n, int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st)
+                             int64_t n, int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st,
+                             const int64_t* sel_rows = nullptr, int64_t n_codes = 0,
+                             const float* sel_scales = nullptr)
 {
-    if (!cb->has_proj) return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st);
-    // OPQ (pq.rs:323-326): gather into scratch, then out = r.dot(P^T)
+    if (!cb->has_proj)
+        return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st, sel_rows, n_codes, sel_scales);
+    // OPQ (pq.rs:323-326): gather into scratch, then out = r.dot(P^T); a lookup's scale comes last
     const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
     PQCHK(ensure_scratch(cb, slot, chunk));
     CodebookDev& cd = cb->dev[slot];
     HIPCHK(hipStreamWaitEvent(st, cd.scratch_done, 0));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t rows = std::min<int64_t>(chunk, n - r0);
-        PQCHK(gather_dev(cb, slot, (const char*)d_codes + r0 * c_rs * code_bytes, code_bytes, rows,
-                         c_rs, cd.scratch, cb->d, st));
+        if (sel_rows)
+            PQCHK(gather_dev(cb, slot, d_codes, code_bytes, rows, c_rs, cd.scratch, cb->d, st, sel_rows + r0, n_codes, nullptr));
+        else
+            PQCHK(gather_dev(cb, slot, (const char*)d_codes + r0 * c_rs * code_bytes, code_bytes, rows,
+                             c_rs, cd.scratch, cb->d, st));
         PQCHK(rotate_dev(cd.scratch, rows, cb->d, cd.PT, (int)cb->d, d_out + r0 * o_rs, o_rs, st));
+        if (sel_rows && sel_scales) {
+            const unsigned g = (unsigned)std::min<int64_t>((rows * cb->d + 255) / 256, 256 * 32);
+            hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, st, d_out + r0 * o_rs, rows, (int)cb->d, o_rs,
+                               sel_rows + r0, n_codes, sel_scales);
+            HIPCHK(hipGetLastError());
+        }
     }
     HIPCHK(hipEventRecord(cd.scratch_done, st));
     return PQHIP_OK;
@@ -835,6 +861,23 @@ int32_t pqhip_reconstruct_batch_f32_dev(pqhip_codebook* cb, int32_t slot, const 
     HIPCHK(hipSetDevice(cb->ctx->devs[slot]->ordinal));
     return reconstruct_dev_impl(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs,
                                 (hipStream_t)stream);
+}
+
+int32_t pqhip_reconstruct_rows_f32_dev(pqhip_codebook* cb, int32_t slot, const void* d_codes,
+                                       int32_t code_bytes, int64_t n_codes, int64_t c_rs,
+                                       const int64_t* d_rows, int64_t n, const float* d_scales,
+                                       float* d_out, int64_t o_rs, void* stream)
+{
+    if (!cb || n < 0 || n_codes < 0) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
+    if (n > 0 && (!d_codes || !d_out || !d_rows)) return PQHIP_EINVAL;
+    if (code_bytes != 1 && code_bytes != 4) return PQHIP_EUNSUPPORTED;
+    if (n > 0 && (c_rs < cb->M || o_rs < cb->d)) return PQHIP_ESHAPE;
+    if (n == 0) return PQHIP_OK;
+    if (n_codes == 0) return PQHIP_ECODE_RANGE;  // every index is out of bounds
+    HIPCHK(hipSetDevice(cb->ctx->devs[slot]->ordinal));
+    return reconstruct_dev_impl(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, (hipStream_t)stream,
+                                d_rows, n_codes, d_scales);
 }
 
 int32_t pqhip_check_codes_dev(pqhip_codebook* cb, int32_t slot, void* stream)

@@ -478,3 +478,47 @@ class Pq:
             if rc != _lib.OK:
                 raise _lib.PqHipError(rc, "pqhip_check_codes_dev")
         return out
+
+    def reconstruct_rows_device(self, codes, rows, scales=None, out=None, stream=None, check=False):
+        """Lookup path of a resident quantized matrix ("next" row):
+        `reconstruct_batch(codes.select(Axis(0), rows)) * scales.select(rows)` in one pass.
+        codes: CUDA uint8 [N, M]; rows: CUDA int64 [n]; scales: None or CUDA float32 [N]."""
+        import torch
+        assert codes.is_cuda and codes.dtype == torch.uint8 and codes.dim() == 2
+        assert rows.is_cuda and rows.dtype == torch.int64 and rows.dim() == 1 and rows.is_contiguous()
+        if codes.shape[1] != self.quantized_len():
+            raise PanicError("Quantization length does not match number of subquantizers")
+        if codes.stride(1) != 1:
+            codes = codes.contiguous()
+        if scales is not None:
+            assert scales.is_cuda and scales.dtype == torch.float32 and scales.is_contiguous()
+            if scales.shape != (codes.shape[0],):
+                raise PanicError("scales must hold one value per code row")
+        n = rows.shape[0]
+        if out is None:
+            out = torch.empty((n, self.reconstructed_len()), dtype=torch.float32, device=codes.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.stride(1) == 1
+        if tuple(out.shape) != (n, self.reconstructed_len()):
+            raise PanicError("Reconstructions matrix has incorrect shape, expected: (%d, %d), got: (%d, %d)"
+                             % (n, self.reconstructed_len(), out.shape[0], out.shape[1]))
+        cb = self._cb()
+        if stream is None:
+            stream = torch.cuda.current_stream(codes.device).cuda_stream
+        slot = self._slot_for(codes)
+        rc = _lib.lib().pqhip_reconstruct_rows_f32_dev(
+            cb, slot, codes.data_ptr(), 1, codes.shape[0],
+            codes.stride(0) if codes.shape[0] > 1 else max(codes.stride(0), codes.shape[1]),
+            rows.data_ptr(), n, scales.data_ptr() if scales is not None else None,
+            out.data_ptr(), out.stride(0) if n > 1 else max(out.stride(0), out.shape[1]),
+            ctypes.c_void_p(stream))
+        if rc == _lib.ECODE_RANGE:
+            raise PanicError("ndarray: index out of bounds")
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_reconstruct_rows_f32_dev")
+        if check:
+            rc = _lib.lib().pqhip_check_codes_dev(cb, slot, ctypes.c_void_p(stream))
+            if rc == _lib.ECODE_RANGE:
+                raise PanicError("ndarray: index out of bounds")
+            if rc != _lib.OK:
+                raise _lib.PqHipError(rc, "pqhip_check_codes_dev")
+        return out

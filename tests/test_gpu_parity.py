@@ -697,3 +697,42 @@ def test_train_pq_statistical_loss(ra, kats):
         ra.train_pq(10, 4, 0, 1, x)
     with pytest.raises(ra.ReductiveError):
         ra.train_pq(10, 4, 10, 0, x)
+
+
+# ---- "next" row 2: lookup path of a resident quantized matrix (select + reconstruct + rescale) ----
+@pytest.mark.parametrize("shape", [(5000, 15, 256, 20, False), (3000, 5, 40, 7, False), (2000, 8, 64, 8, True),
+                                   (900, 3, 300, 6, False), (400, 4200, 2, 1, False)])
+def test_lookup_rows_matches_select_reconstruct_scale(ra, shape):
+    import torch
+    N, M, K, dsub, opq = shape
+    d = M * dsub
+    q = synth.normalish(1100 + N, (M, K, dsub))
+    P = synth.orthonormal(1101 + N, d) if opq else None
+    codes = synth.codes_u8(1102 + N, (N, M), min(K, 256))
+    scales = np.abs(synth.normalish(1103 + N, (N,))) + np.float32(0.5)
+    n = 3333
+    pick = synth.codes_u8(1104 + N, (n, 3), 256).astype(np.int64)
+    rows = (pick[:, 0] * 65536 + pick[:, 1] * 256 + pick[:, 2]) % N          # repeats and any order
+    pq = _pq(ra, q, P)
+    want = orc.reconstruct_batch(q, codes[rows], projection=P)
+    dev = torch.device("cuda:0")
+    tc, tr, ts = torch.from_numpy(codes).to(dev), torch.from_numpy(rows).to(dev), torch.from_numpy(scales).to(dev)
+    got = pq.reconstruct_rows_device(tc, tr, check=True).cpu().numpy()
+    assert got.tobytes() == want.tobytes()
+    got_s = pq.reconstruct_rows_device(tc, tr, scales=ts, check=True).cpu().numpy()
+    assert got_s.tobytes() == (want * scales[rows][:, None]).astype(np.float32).tobytes()
+    # strided code matrix and output
+    cbuf = torch.zeros((N, M + 3), dtype=torch.uint8, device=dev)
+    cbuf[:, :M] = tc
+    obuf = torch.full((n, d + 4), -3.0, dtype=torch.float32, device=dev)
+    pq.reconstruct_rows_device(cbuf[:, :M], tr, scales=ts, out=obuf[:, :d], check=True)
+    assert obuf[:, :d].cpu().numpy().tobytes() == got_s.tobytes() and (obuf[:, d:] == -3.0).all().item()
+    # ndarray `select` panics on an index out of bounds
+    bad = tr.clone()
+    bad[17] = N
+    with pytest.raises(ra.PanicError):
+        pq.reconstruct_rows_device(tc, bad, check=True)
+    bad[17] = -1
+    with pytest.raises(ra.PanicError):
+        pq.reconstruct_rows_device(tc, bad, scales=ts, check=True)
+    assert pq.reconstruct_rows_device(tc, tr[:0]).shape == (0, d)
