@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mfma(EncodeArgs a)
 
     // operands of one 32-row tile: B fragments (k = 2s + h of the lane's row) and ||x||^2
     auto prep_tile = [&](const float (&v)[DP], float (&bop)[S], float& xx) {
-        xx = norm_unrolled_padded<DP>(v, dsub);
+        xx = VEC ? norm_unrolled_static<DP>(v) : norm_unrolled_padded<DP>(v, dsub);  // VEC implies dsub == DP
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = h ? v[2 * s + 1] : v[2 * s];
     };

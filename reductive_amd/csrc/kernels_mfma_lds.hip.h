@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mfma_lds(EncodeArgs a)
         }
     };
     auto prep_tile = [&](const float (&v)[DP], float (&bop)[S], float& xx) {
-        xx = norm_unrolled_padded<DP>(v, dsub);
+        xx = VEC ? norm_unrolled_static<DP>(v) : norm_unrolled_padded<DP>(v, dsub);  // VEC implies dsub == DP
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = h ? v[2 * s + 1] : v[2 * s];
     };
@@ -282,7 +282,11 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
         }
     };
     auto prep_tile = [&](const f32x2 (&v2)[DP / 2], float (&bop)[S], float& xx) {
-        if (dsub == DP) {
+        // VEC implies dsub == DP (dispatch rule): deciding it at compile time matters -- with a
+        // run-time test the compiler if-converts and executes BOTH norms for every tile (~100 VALU)
+        if (VEC) {
+            xx = norm_unrolled_packed<DP>(v2);
+        } else if (dsub == DP) {
             xx = norm_unrolled_packed<DP>(v2);
         } else {
             float v[DP];
