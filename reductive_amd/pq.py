@@ -126,9 +126,13 @@ def kmeans_iterations(quantizers, instances, n_iterations=1, want_loss=True, ctx
     q = np.array(quantizers, dtype=np.float32, order="C", copy=True)
     if q.ndim == 2:
         q = q[None]
+    if not hasattr(instances, "is_cuda"):
+        instances = np.asarray(instances, dtype=np.float32)
     if q.ndim != 3 or q.shape[1] == 0:
         raise PanicError("Cannot cluster instances with zero centroids.")        # kmeans.rs:260-263
     M, K, dsub = q.shape
+    if instances.ndim != 2 or instances.shape[1] != M * dsub:
+        raise PanicError("Centroid and instance lengths differ.")                # kmeans.rs:264-268
     ctx = ctx or default_ctx()
     loss = np.zeros(M, np.float32) if want_loss else None
     fp = ctypes.POINTER(ctypes.c_float)

@@ -99,6 +99,32 @@ def test_batch_path_fails_loudly_without_a_gpu(ra):
         pq.reconstruct_batch(np.zeros((3, 2), np.uint8))
 
 
+def test_training_and_lookup_entry_points_fail_loudly_without_a_gpu(ra):
+    """The "next" rows have no CPU fallback either; argument errors are reported before any device work."""
+    n = ctypes.c_int32(-1)
+    rc = ra.lib().pqhip_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    x = synth.normalish(8, (50, 6))
+    with pytest.raises(ra.PqHipError, match="no usable HIP device"):
+        ra.kmeans_iterations(synth.normalish(9, (2, 4, 3)), x, 2)
+    with pytest.raises(ra.PqHipError, match="no usable HIP device"):
+        ra.cluster_assignments(synth.normalish(9, (4, 6)), x)
+    with pytest.raises(ra.PqHipError):
+        ra.train_pq(2, 2, 3, 1, x)
+    # host-side checks that mirror the reference's asserts come first
+    with pytest.raises(ra.PanicError, match="Centroid and instance lengths differ"):
+        ra.kmeans_iterations(synth.normalish(9, (2, 4, 3)), synth.normalish(8, (50, 7)), 1)
+    with pytest.raises(ra.PanicError, match="zero centroids"):
+        ra.kmeans_iterations(np.zeros((2, 0, 3), np.float32), x, 1)
+    with pytest.raises(ra.ReductiveError, match="between 1 and 6, was 7"):
+        ra.train_pq(7, 2, 3, 1, x)
+    with pytest.raises(ra.ReductiveError, match="bits must be between 1 and 5"):
+        ra.train_pq(2, 6, 3, 1, x)            # log2(50) truncates to 5 (pq.rs:76-81)
+    with pytest.raises(ra.ReductiveError, match="iterations must be >= 1"):
+        ra.train_pq(2, 2, 0, 1, x)
+
+
 def test_bench_sharding_two_ranks_gloo():
     """bench.py's N>1 path on CPU: world_size 2 over gloo, --dry-run (no GPU work):
     every rank takes its own shard, timing is max-reduced, rank 0 prints one JSON line."""
