@@ -1,10 +1,12 @@
-// encode_launch.hip -- compiled once per (PQ_KIND, PQ_T) by the Makefile.
+// encode_launch.hip -- compiled once per (PQ_KIND, PQ_T, PQ_DPSET) by the Makefile.
+// PQ_KIND 0: VALU-argmin kernel, 2: LDS-argmin kernel with LDS-resident fragments (the default).
+// PQ_DPSET 0: padded sub-dimension DP = 0 (mod 4), 1: DP = 2 (mod 4).
 #include "encode_launch.h"
 #include <cstdlib>
 #include "kernels_mfma_lds.hip.h"
 
-#ifndef PQ_KIND
-#error "PQ_KIND and PQ_T must be defined"
+#if !defined(PQ_KIND) || !defined(PQ_T) || !defined(PQ_DPSET)
+#error "PQ_KIND, PQ_T and PQ_DPSET must be defined"
 #endif
 
 namespace pqhip {
@@ -30,9 +32,6 @@ static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid,
     if (KIND == 0) {
         if (vec) hipLaunchKernelGGL((k_encode_mfma<T, DP, true, uint8_t>), grid, dim3(256), pad, st, a);
         else hipLaunchKernelGGL((k_encode_mfma<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
-    } else if (KIND == 1) {
-        if (vec) hipLaunchKernelGGL((k_encode_mfma_lds<T, DP, true, uint8_t>), grid, dim3(256), pad, st, a);
-        else hipLaunchKernelGGL((k_encode_mfma_lds<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
     } else {
         if (vec) hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, true, uint8_t>), grid, dim3(256), pad, st, a);
         else hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
@@ -40,22 +39,36 @@ static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid,
     return true;
 }
 
-template <int KIND, int T>
+template <int KIND, int T, int DPSET>
 bool launch_encode_mfma_t(int DP, bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st)
 {
-    switch (DP) {
-    case 4: return launch_vec<KIND, T, 4>(vec, code_bytes, a, grid, st);
-    case 8: return launch_vec<KIND, T, 8>(vec, code_bytes, a, grid, st);
-    case 12: return launch_vec<KIND, T, 12>(vec, code_bytes, a, grid, st);
-    case 16: return launch_vec<KIND, T, 16>(vec, code_bytes, a, grid, st);
-    case 20: return launch_vec<KIND, T, 20>(vec, code_bytes, a, grid, st);
-    case 24: return launch_vec<KIND, T, 24>(vec, code_bytes, a, grid, st);
-    case 28: return launch_vec<KIND, T, 28>(vec, code_bytes, a, grid, st);
-    case 32: return launch_vec<KIND, T, 32>(vec, code_bytes, a, grid, st);
-    default: return false;
+    if (DPSET == 0) {
+        switch (DP) {
+        case 4: return launch_vec<KIND, T, 4>(vec, code_bytes, a, grid, st);
+        case 8: return launch_vec<KIND, T, 8>(vec, code_bytes, a, grid, st);
+        case 12: return launch_vec<KIND, T, 12>(vec, code_bytes, a, grid, st);
+        case 16: return launch_vec<KIND, T, 16>(vec, code_bytes, a, grid, st);
+        case 20: return launch_vec<KIND, T, 20>(vec, code_bytes, a, grid, st);
+        case 24: return launch_vec<KIND, T, 24>(vec, code_bytes, a, grid, st);
+        case 28: return launch_vec<KIND, T, 28>(vec, code_bytes, a, grid, st);
+        case 32: return launch_vec<KIND, T, 32>(vec, code_bytes, a, grid, st);
+        default: return false;
+        }
+    } else {
+        switch (DP) {
+        case 2: return launch_vec<KIND, T, 2>(vec, code_bytes, a, grid, st);
+        case 6: return launch_vec<KIND, T, 6>(vec, code_bytes, a, grid, st);
+        case 10: return launch_vec<KIND, T, 10>(vec, code_bytes, a, grid, st);
+        case 14: return launch_vec<KIND, T, 14>(vec, code_bytes, a, grid, st);
+        case 18: return launch_vec<KIND, T, 18>(vec, code_bytes, a, grid, st);
+        case 22: return launch_vec<KIND, T, 22>(vec, code_bytes, a, grid, st);
+        case 26: return launch_vec<KIND, T, 26>(vec, code_bytes, a, grid, st);
+        case 30: return launch_vec<KIND, T, 30>(vec, code_bytes, a, grid, st);
+        default: return false;
+        }
     }
 }
 
-template bool launch_encode_mfma_t<PQ_KIND, PQ_T>(int, bool, int, const EncodeArgs&, dim3, hipStream_t);
+template bool launch_encode_mfma_t<PQ_KIND, PQ_T, PQ_DPSET>(int, bool, int, const EncodeArgs&, dim3, hipStream_t);
 
 }  // namespace pqhip

@@ -84,7 +84,7 @@ __device__ __forceinline__ void encode_tile_slow(const EncodeArgs& a, int m, int
 // the M sub-vector slices of an x row are pulled from HBM once and then hit that XCD's L2.
 //
 // T  : centroid tiles (K padded to 32 T with +inf-norm dummies)
-// DP : dsub padded to a multiple of 4 (zero k-padding is exact: fma(0, 0, acc) == acc)
+// DP : dsub padded to an even number (zero k-padding is exact: fma(0, 0, acc) == acc)
 // VEC: x rows are 16-byte aligned and dsub % 4 == 0 -> global_load_dwordx4
 // ---------------------------------------------------------------------------------------------
 template <int T, int DP, bool VEC, typename IdxT>
@@ -136,11 +136,17 @@ __global__ __launch_bounds__(256, 2) void k_encode_mfma(EncodeArgs a)
         int64_t row = tile_row0 + j;
         if (row >= a.n) row = a.n - 1;  // clamp: loads stay in bounds, result is not stored
         const float* p = xcol + row * a.x_rs;
-        if (VEC) {
+        if (VEC && DP % 4 == 0) {
 #pragma unroll
             for (int e = 0; e < DP; e += 4) {
                 const f32x4 q = *reinterpret_cast<const f32x4*>(p + e);
                 v[e] = q[0]; v[e + 1] = q[1]; v[e + 2] = q[2]; v[e + 3] = q[3];
+            }
+        } else if (VEC) {  // DP = 2 (mod 4): 8-byte groups
+#pragma unroll
+            for (int e = 0; e < DP; e += 2) {
+                const f32x2 q = *reinterpret_cast<const f32x2*>(p + e);
+                v[e] = q[0]; v[e + 1] = q[1];
             }
         } else {
 #pragma unroll

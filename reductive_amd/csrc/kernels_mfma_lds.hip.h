@@ -20,199 +20,6 @@
 
 namespace pqhip {
 
-template <int T, int DP, bool VEC, typename IdxT>
-__global__ __launch_bounds__(256, 2) void k_encode_mfma_lds(EncodeArgs a)
-{
-    constexpr int S = DP / 2;
-    // one region per wave: T slots x 64 lanes of 64-bit keys, then T*32 centroid norms
-    __shared__ __attribute__((aligned(16))) long long slot_s[4][T][64];
-    __shared__ __attribute__((aligned(16))) float cc_s[4][T * 32];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31;
-    const int h = lane >> 5;
-
-    // ---- item mapping (wave-uniform), identical to k_encode_mfma ----
-    const int64_t b = blockIdx.x;
-    const int xcd = (int)(b & 7);
-    const int64_t sidx = (b >> 3) * 4 + wave;
-    const int64_t chunk_local = sidx / a.M;
-    const int m = (int)(sidx - chunk_local * a.M);
-    const int64_t chunk = chunk_local * 8 + xcd;
-    const bool active = (chunk_local < a.chunks_per_xcd) && (chunk < a.n_chunks);
-
-    constexpr long long kKeyInit = 0x7fffffffffffffffll;
-    float af[T][S];
-    if (active) {
-        const float* fp = a.frags + (int64_t)m * T * S * 64 + lane;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int s = 0; s < S; ++s) af[t][s] = fp[(t * S + s) * 64];
-        const float* ccm = a.cc + (int64_t)m * T * 32;
-        for (int i = lane; i < T * 32; i += 64) cc_s[wave][i] = ccm[i];
-#pragma unroll
-        for (int t = 0; t < T; ++t) slot_s[wave][t][lane] = kKeyInit;
-    } else {
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int s = 0; s < S; ++s) af[t][s] = 0.f;
-    }
-    __syncthreads();
-    if (!active) return;
-
-    const int64_t row_begin = chunk * a.rows_per_item;
-    int64_t row_end = row_begin + a.rows_per_item;
-    if (row_end > a.n) row_end = a.n;
-    const float* xcol = a.x + (int64_t)m * a.dsub;
-    const int dsub = a.dsub;
-
-    auto load_tile = [&](float (&v)[DP], int64_t tile_row0) {
-        int64_t row = tile_row0 + j;
-        if (row >= a.n) row = a.n - 1;
-        const float* p = xcol + row * a.x_rs;
-        if (VEC) {
-#pragma unroll
-            for (int e = 0; e < DP; e += 4) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(p + e);
-                v[e] = q[0]; v[e + 1] = q[1]; v[e + 2] = q[2]; v[e + 3] = q[3];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < DP; ++e) v[e] = (e < dsub) ? p[e] : 0.f;
-        }
-    };
-    auto prep_tile = [&](const float (&v)[DP], float (&bop)[S], float& xx) {
-        xx = VEC ? norm_unrolled_static<DP>(v) : norm_unrolled_padded<DP>(v, dsub);  // VEC implies dsub == DP
-#pragma unroll
-        for (int s = 0; s < S; ++s) bop[s] = h ? v[2 * s + 1] : v[2 * s];
-    };
-
-    // low words of the keys: offset of accumulator register r inside its 32-centroid tile
-    // (without the half-wave's +4).  Made opaque so they stay resident in 16 VGPRs.
-    int lo[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        lo[r] = (r & 3) + 8 * (r >> 2);
-        asm volatile("" : "+v"(lo[r]));
-    }
-
-    const int64_t last_tile0 = row_begin + ((row_end - row_begin - 1) / 32) * 32;
-    float vn[DP];
-    float bop[S];
-    float xx;
-    load_tile(vn, row_begin);
-    prep_tile(vn, bop, xx);
-    load_tile(vn, (row_begin + 32 <= last_tile0) ? row_begin + 32 : last_tile0);
-
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][s], bop[s], acc, 0, 0, 0);
-
-    for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
-        float bop_n[S];
-        float xx_n;
-        prep_tile(vn, bop_n, xx_n);
-        load_tile(vn, (row0 + 64 <= last_tile0) ? row0 + 64 : last_tile0);
-        const f32x2 xx2 = {xx, xx};
-
-        // ||c||^2 of the lane's 16 centroids of tile t: centroids 32t + 8g + 4h + {0..3}, g = 0..3.
-        // Always fetched one step ahead and BEFORE the previous step's atomics are queued: the LDS
-        // pipe is in-order, a read queued behind 16 atomics would wait for all of them.
-        auto read_cc = [&](int t, f32x4 (&c)[4]) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                c[g] = *reinterpret_cast<const f32x4*>(&cc_s[wave][32 * t + 8 * g + 4 * h]);
-        };
-        f32x4 c4[4];
-        read_cc(0, c4);
-
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            // everything queued on the LDS pipe so far (the previous step's atomics, this step's
-            // norms) has had a whole 640-cycle chain to retire: this wait is normally free, and it
-            // keeps the compiler from waiting on the reads issued just below instead
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 c4n[4];
-            read_cc((t + 1) % T, c4n);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- VALU: 16 distances -> 16 keys ----
-            long long key[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x2 c01 = {c4[g][0], c4[g][1]}, c23 = {c4[g][2], c4[g][3]};
-                f32x2 t01, t23;  // v_pk_add_f32 = two independent IEEE adds (rule 3, first rounding)
-                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t01) : "v"(xx2), "v"(c01));
-                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t23) : "v"(xx2), "v"(c23));
-                const float tt[4] = {t01[0], t01[1], t23[0], t23[1]};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = 4 * g + q;
-                    const float d = ffma(acc[r], -2.0f, tt[q]);  // == fl(tt - fl(dp + dp))
-                    key[r] = ((long long)__float_as_int(d) << 32) | (long long)(unsigned)lo[r];
-                }
-                // keep tt alive past the fma: stops the 2-address (v_fmac + v_mov) form, so the
-                // fma writes the key's high register directly
-                asm volatile("" ::"v"(t01), "v"(t23));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- matrix core: next chain; LDS: fold this tile's keys (overlaps the MFMAs) ----
-            f32x16 nacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
-                           0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            long long* slot = &slot_s[wave][t][lane];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if (t + 1 < T)
-                    nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t + 1][s], bop[s], nacc, 0, 0, 0);
-                else
-                    nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][s], bop_n[s], nacc, 0, 0, 0);
-#pragma unroll
-                for (int r = (16 * s) / S; r < (16 * (s + 1)) / S; ++r)
-                    (void)__hip_atomic_fetch_min(slot, key[r], __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc = nacc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) c4[g] = c4n[g];
-        }
-
-        // ---- fold the T slots of this row (tiles in ascending order, strict <: first minimum) ----
-        float best = __builtin_inff();
-        int bidx = 0;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const long long k = slot_s[wave][t][lane];
-            slot_s[wave][t][lane] = kKeyInit;
-            const float d = __int_as_float((int)(k >> 32));
-            const bool lt = d < best;
-            best = lt ? d : best;
-            bidx = lt ? ((int)(unsigned)k + 32 * t) : bidx;
-        }
-        const bool neg = best < 0.f;  // signed-integer key order is only valid for d >= 0
-        bidx += 4 * h;
-        const float od = __shfl_xor(best, 32);
-        const int oi = __shfl_xor(bidx, 32);
-        if (od < best || (od == best && oi < bidx)) bidx = oi;
-
-        const int64_t row = row0 + j;
-        const bool valid = row < a.n;
-        if (__builtin_amdgcn_ballot_w64(!(xx < kBigNorm) || neg) != 0ull) {
-            // rare: NaN / Inf / huge, or a row that sits on a centroid -> exact scalar evaluation
-            encode_tile_slow<IdxT>(a, m, row, valid);
-        } else if (h == 0 && valid) {
-            reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
-        }
-#pragma unroll
-        for (int s = 0; s < S; ++s) bop[s] = bop_n[s];
-        xx = xx_n;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // K1, third generation: as k_encode_mfma_lds, but the sub-codebook's MFMA fragments live in a
 // per-workgroup LDS image instead of 80 resident VGPRs, so THREE waves fit on a SIMD (<= 168
@@ -268,13 +75,16 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
     auto load_tile = [&](f32x2 (&v2)[DP / 2], int64_t tile_row0) {
         const int left = (int)((a.n - tile_row0 < 32) ? a.n - tile_row0 : 32);  // wave-uniform
         const float* p = (j < left) ? xcol + (tile_row0 + j) * a.x_rs : plast;
-        if (VEC) {
+        if (VEC && DP % 4 == 0) {
 #pragma unroll
             for (int e = 0; e < DP; e += 4) {
                 const f32x4 qv = *reinterpret_cast<const f32x4*>(p + e);
                 v2[e / 2] = (f32x2){qv[0], qv[1]};
                 v2[e / 2 + 1] = (f32x2){qv[2], qv[3]};
             }
+        } else if (VEC) {  // DP = 2 (mod 4): 8-byte groups
+#pragma unroll
+            for (int e = 0; e < DP; e += 2) v2[e / 2] = *reinterpret_cast<const f32x2*>(p + e);
         } else {
 #pragma unroll
             for (int e = 0; e < DP; e += 2)

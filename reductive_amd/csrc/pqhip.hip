@@ -152,11 +152,12 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         a.x = d_x; a.n = n; a.x_rs = x_rs; a.out = d_codes; a.o_rs = o_rs;
         a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
         a.M = (int)cb->M; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
-        // kernel kind: 0 VALU argmin, 1 LDS argmin (2 waves/SIMD), 2 LDS argmin + LDS A fragments
+        // kernel kind: 0 VALU argmin, 2 LDS argmin + LDS A fragments (variant 3, the retired
+        // register-resident LDS-argmin kernel, is an alias of the default)
         // auto: for sub-vectors of <= 4 floats the per-distance work outweighs the MFMA chain and the
         // LDS pipe (one atomic per 64 distances) becomes the bound: the VALU-argmin kernel is 10-15 % faster
         const bool tiny = cb->variant == 0 && cb->DP <= 4 && code_bytes == 1;
-        const int kind = (cb->variant == 2 || tiny) ? 0 : cb->variant == 3 ? 1 : 2;
+        const int kind = (cb->variant == 2 || tiny) ? 0 : 2;
         dim3 grid;
         if (kind == 2) {
             // one workgroup = one subquantizer x 4 row streams (one per wave)
@@ -178,13 +179,15 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
             const int64_t wgs_per_xcd = (items_per_xcd + 3) / 4;
             grid = dim3((unsigned)(wgs_per_xcd * 8));
         }
-        const bool vec = (cb->dsub % 4 == 0) && (cb->DP == cb->dsub) && (x_rs % 4 == 0) &&
-                         ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
+        // widest aligned loads: 16-byte groups when dsub = 0 (mod 4), 8-byte groups when dsub = 2 (mod 4)
+        const int grp = (cb->DP % 4 == 0) ? 4 : 2;
+        const bool vec = (cb->DP == cb->dsub) && (x_rs % grp == 0) &&
+                         ((reinterpret_cast<uintptr_t>(d_x) & (uintptr_t)(4 * grp - 1)) == 0);
         if (!launch_encode_mfma(kind, cb->T, cb->DP, vec, code_bytes, a, grid, st)) return PQHIP_EUNSUPPORTED;
-        static const char* const names[3][2] = {{"k_encode_mfma<scalar-load>", "k_encode_mfma<vec4>"},
-                                                {"k_encode_mfma_lds<scalar-load>", "k_encode_mfma_lds<vec4>"},
-                                                {"k_encode_mfma_lds3<scalar-load>", "k_encode_mfma_lds3<vec4>"}};
-        cb->last_kernel = names[kind][vec ? 1 : 0];
+        static const char* const names[3][3] = {{"k_encode_mfma<scalar-load>", "k_encode_mfma<vec2>", "k_encode_mfma<vec4>"},
+                                                {"", "", ""},
+                                                {"k_encode_mfma_lds3<scalar-load>", "k_encode_mfma_lds3<vec2>", "k_encode_mfma_lds3<vec4>"}};
+        cb->last_kernel = names[kind][vec ? grp / 2 : 0];
     } else {
         const int64_t total = n * cb->M;
         const int block = 256;
@@ -314,13 +317,13 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
     cb->ctx = ctx;
     cb->M = M; cb->K = K; cb->dsub = dsub; cb->d = M * dsub;
     cb->has_proj = projection != nullptr;
-    // MFMA geometry: K <= 256 padded to {1,2,4,8} tiles of 32; dsub <= 32 padded to a multiple
-    // of 4; resident A fragments must fit the register file (T * DP/2 <= 128).
+    // MFMA geometry: K <= 256 padded to {1,2,4,8} tiles of 32; dsub <= 32 padded to an even
+    // number of k (one MFMA consumes two); A fragments must fit (T * DP/2 <= 128).
     int T = 0, DP = 0;
     if (K <= 256 && dsub <= 32) {
         const int tiles = (int)((K + 31) / 32);
         T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
-        DP = (int)round_up(dsub, 4);
+        DP = (int)round_up(dsub, 2);
         if (T * (DP / 2) > 128) { T = 0; DP = 0; }
     }
     cb->T = T; cb->DP = DP;
