@@ -565,8 +565,9 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
         HIPCHK(hipGetLastError());
         return PQHIP_OK;
     }
+    static const int rec_wgs_per_cu = [] { const char* e = getenv("PQHIP_DEBUG_REC_WGS"); return e ? std::max(1, atoi(e)) : 8; }();
     const unsigned grid =
-        (unsigned)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, 256 * 8);
+        (unsigned)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, (int64_t)256 * rec_wgs_per_cu);
     const size_t lds = (((size_t)cpr * sizeof(int) + 15) & ~(size_t)15) +
                        (((size_t)2 * rows_per_block * cb->M * code_bytes + 15) & ~(size_t)15) +
                        (sel_rows ? (size_t)2 * rows_per_block * sizeof(float) : 0);
