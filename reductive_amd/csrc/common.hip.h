@@ -141,6 +141,32 @@ __device__ __forceinline__ float norm_unrolled_packed(const f32x2 (&v2)[D / 2])
     return s;
 }
 
+// Dword-aligned wide loads.  ROCm runs the GPU in unaligned-access mode: global_load_dwordx4 / x2
+// accept any 4-byte-aligned address, and the compiler emits them for these under-aligned vector
+// types.  So a row of floats never needs a scalar-load variant because of where it starts.
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
+typedef f32x2 f32x2_u __attribute__((aligned(4)));
+
+// v[0 .. CNT) = p[0 .. CNT) with the widest loads available, v[CNT .. N) = 0.
+template <int CNT, int N>
+__device__ __forceinline__ void load_row_floats(const float* __restrict__ p, float (&v)[N])
+{
+    static_assert(CNT <= N, "row longer than its register image");
+    constexpr int N4 = (CNT / 4) * 4, N2 = N4 + ((CNT - N4) / 2) * 2;
+#pragma unroll
+    for (int e = 0; e < N4; e += 4) {
+        const f32x4 q = *reinterpret_cast<const f32x4_u*>(p + e);
+        v[e] = q[0]; v[e + 1] = q[1]; v[e + 2] = q[2]; v[e + 3] = q[3];
+    }
+    if (N2 > N4) {
+        const f32x2 q = *reinterpret_cast<const f32x2_u*>(p + N4);
+        v[N4] = q[0]; v[N4 + 1] = q[1];
+    }
+    if (CNT > N2) v[N2] = p[N2];
+#pragma unroll
+    for (int e = CNT; e < N; ++e) v[e] = 0.f;
+}
+
 // One sequential fmaf chain with restarts every kKC (rule 2), global operands with strides.
 __device__ inline float chain_dot_global(const float* __restrict__ a, int64_t as,
                                          const float* __restrict__ b, int64_t bs, int n)

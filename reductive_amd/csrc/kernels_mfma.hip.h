@@ -130,33 +130,25 @@ __global__ __launch_bounds__(256, 2) void k_encode_mfma(EncodeArgs a)
     int64_t row_end = row_begin + a.rows_per_item;
     if (row_end > a.n) row_end = a.n;
     const float* xcol = a.x + (int64_t)m * a.dsub;
-    const int dsub = a.dsub;
 
     auto load_tile = [&](float (&v)[DP], int64_t tile_row0) {
         int64_t row = tile_row0 + j;
         if (row >= a.n) row = a.n - 1;  // clamp: loads stay in bounds, result is not stored
         const float* p = xcol + row * a.x_rs;
-        if (VEC && DP % 4 == 0) {
-#pragma unroll
-            for (int e = 0; e < DP; e += 4) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(p + e);
-                v[e] = q[0]; v[e + 1] = q[1]; v[e + 2] = q[2]; v[e + 3] = q[3];
-            }
-        } else if (VEC) {  // DP = 2 (mod 4): 8-byte groups
-#pragma unroll
-            for (int e = 0; e < DP; e += 2) {
-                const f32x2 q = *reinterpret_cast<const f32x2*>(p + e);
-                v[e] = q[0]; v[e + 1] = q[1];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < DP; ++e) v[e] = (e < dsub) ? p[e] : 0.f;
-        }
+        // VEC: all DP floats are real (dsub == DP); otherwise dsub == DP - 1 and the last one is padding
+        load_row_floats<VEC ? DP : DP - 1, DP>(p, v);
     };
 
     // operands of one 32-row tile: B fragments (k = 2s + h of the lane's row) and ||x||^2
     auto prep_tile = [&](const float (&v)[DP], float (&bop)[S], float& xx) {
-        xx = VEC ? norm_unrolled_static<DP>(v) : norm_unrolled_padded<DP>(v, dsub);  // VEC implies dsub == DP
+        if (VEC) {
+            xx = norm_unrolled_static<DP>(v);
+        } else {  // dsub == DP - 1, known at compile time
+            float w[DP - 1];
+#pragma unroll
+            for (int e = 0; e < DP - 1; ++e) w[e] = v[e];
+            xx = norm_unrolled_static<DP - 1>(w);
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = h ? v[2 * s + 1] : v[2 * s];
     };

@@ -67,7 +67,6 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
     int64_t row_end = row_begin + a.rows_per_item;
     if (row_end > a.n) row_end = a.n;
     const float* xcol = a.x + (int64_t)m * a.dsub;
-    const int dsub = a.dsub;
 
     // x tile: lane j reads the DP floats of its row's sub-vector.  Rows past the end are clamped
     // to the last row (their result is never stored).
@@ -75,34 +74,22 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
     auto load_tile = [&](f32x2 (&v2)[DP / 2], int64_t tile_row0) {
         const int left = (int)((a.n - tile_row0 < 32) ? a.n - tile_row0 : 32);  // wave-uniform
         const float* p = (j < left) ? xcol + (tile_row0 + j) * a.x_rs : plast;
-        if (VEC && DP % 4 == 0) {
+        // VEC: all DP floats are real (dsub == DP); otherwise dsub == DP - 1 and the last one is padding
+        float v[DP];
+        load_row_floats<VEC ? DP : DP - 1, DP>(p, v);
 #pragma unroll
-            for (int e = 0; e < DP; e += 4) {
-                const f32x4 qv = *reinterpret_cast<const f32x4*>(p + e);
-                v2[e / 2] = (f32x2){qv[0], qv[1]};
-                v2[e / 2 + 1] = (f32x2){qv[2], qv[3]};
-            }
-        } else if (VEC) {  // DP = 2 (mod 4): 8-byte groups
-#pragma unroll
-            for (int e = 0; e < DP; e += 2) v2[e / 2] = *reinterpret_cast<const f32x2*>(p + e);
-        } else {
-#pragma unroll
-            for (int e = 0; e < DP; e += 2)
-                v2[e / 2] = (f32x2){(e < dsub) ? p[e] : 0.f, (e + 1 < dsub) ? p[e + 1] : 0.f};
-        }
+        for (int e = 0; e < DP; e += 2) v2[e / 2] = (f32x2){v[e], v[e + 1]};
     };
     auto prep_tile = [&](const f32x2 (&v2)[DP / 2], float (&bop)[S], float& xx) {
-        // VEC implies dsub == DP (dispatch rule): deciding it at compile time matters -- with a
-        // run-time test the compiler if-converts and executes BOTH norms for every tile (~100 VALU)
+        // the sub-dimension is a compile-time fact (DP or DP - 1): with a run-time test the compiler
+        // if-converts and executes BOTH norm variants for every tile (~100 VALU)
         if (VEC) {
             xx = norm_unrolled_packed<DP>(v2);
-        } else if (dsub == DP) {
-            xx = norm_unrolled_packed<DP>(v2);
         } else {
-            float v[DP];
+            float v[DP - 1];
 #pragma unroll
-            for (int e = 0; e < DP; ++e) v[e] = v2[e / 2][e & 1];
-            xx = norm_unrolled_padded<DP>(v, dsub);
+            for (int e = 0; e < DP - 1; ++e) v[e] = v2[e / 2][e & 1];
+            xx = norm_unrolled_static<DP - 1>(v);
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = h ? v2[s][1] : v2[s][0];

@@ -179,14 +179,14 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
             const int64_t wgs_per_xcd = (items_per_xcd + 3) / 4;
             grid = dim3((unsigned)(wgs_per_xcd * 8));
         }
-        // widest aligned loads: 16-byte groups when dsub = 0 (mod 4), 8-byte groups when dsub = 2 (mod 4)
+        // template flag: every one of the DP floats of a sub-vector is real (dsub == DP), or the last
+        // one is padding (odd dsub).  Row alignment does not matter: the loads are dword-aligned wide loads.
+        const bool vec = cb->DP == cb->dsub;
         const int grp = (cb->DP % 4 == 0) ? 4 : 2;
-        const bool vec = (cb->DP == cb->dsub) && (x_rs % grp == 0) &&
-                         ((reinterpret_cast<uintptr_t>(d_x) & (uintptr_t)(4 * grp - 1)) == 0);
         if (!launch_encode_mfma(kind, cb->T, cb->DP, vec, code_bytes, a, grid, st)) return PQHIP_EUNSUPPORTED;
-        static const char* const names[3][3] = {{"k_encode_mfma<scalar-load>", "k_encode_mfma<vec2>", "k_encode_mfma<vec4>"},
+        static const char* const names[3][3] = {{"k_encode_mfma<odd>", "k_encode_mfma<vec2>", "k_encode_mfma<vec4>"},
                                                 {"", "", ""},
-                                                {"k_encode_mfma_lds3<scalar-load>", "k_encode_mfma_lds3<vec2>", "k_encode_mfma_lds3<vec4>"}};
+                                                {"k_encode_mfma_lds3<odd>", "k_encode_mfma_lds3<vec2>", "k_encode_mfma_lds3<vec4>"}};
         cb->last_kernel = names[kind][vec ? grp / 2 : 0];
     } else {
         const int64_t total = n * cb->M;

@@ -15,6 +15,9 @@ done <<LIST
 300 75 256 4000000
 300 30 256 10000000
 300 10 256 10000000
+300 20 256 10000000
+300 60 256 4000000
+300 100 256 4000000
 768 48 256 4000000
 768 96 256 4000000
 768 24 256 4000000
