@@ -118,7 +118,10 @@ __global__ void k_rotate_scalar(const float* __restrict__ x, int64_t n, int64_t 
 // reconstruction of code row sel_rows[i] of a resident [n_codes][M] matrix, times
 // sel_scales[sel_rows[i]] when scales are given (one rounded f32 multiply per element); a row index
 // outside [0, n_codes) raises *err like an out-of-range code (ndarray `select` panics) and yields row 0.
-template <typename IdxT, int VEC, bool SEL = false>
+// G = floats fetched per codebook access inside a 16-byte output chunk: 4 when sub-vectors are made
+// of 16-byte groups, 2 or 1 when a chunk spans several sub-vectors (dsub = 2, 6, 10, .. / odd dsub);
+// the store is one dword-aligned 16-byte store either way.
+template <typename IdxT, int VEC, bool SEL = false, int G = VEC>
 __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ codes, int64_t n,
                                                      int64_t c_rs, float* __restrict__ out,
                                                      int64_t o_rs, const float* __restrict__ cb,
@@ -137,14 +140,16 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int d = M * dsub;
     const int cpr = d / VEC;  // chunks per row
-    int* tbl = reinterpret_cast<int*>(smem);  // [cpr]: m | (e << 16)
+    constexpr int NG = VEC / G;               // codebook accesses per chunk
+    const int ntbl = cpr * NG;
+    int* tbl = reinterpret_cast<int*>(smem);  // [cpr * NG]: m | (e << 16) of every G-float group
     const int ncode = rows_per_block * M;
-    IdxT* cl = reinterpret_cast<IdxT*>(smem + (((size_t)cpr * 4 + 15) & ~(size_t)15));  // [2][ncode]
+    IdxT* cl = reinterpret_cast<IdxT*>(smem + (((size_t)ntbl * 4 + 15) & ~(size_t)15));  // [2][ncode]
     // SEL: per-row scale of the current and of the next block, behind the codes
-    float* scl = reinterpret_cast<float*>(smem + (((size_t)cpr * 4 + 15) & ~(size_t)15) +
+    float* scl = reinterpret_cast<float*>(smem + (((size_t)ntbl * 4 + 15) & ~(size_t)15) +
                                           (((size_t)2 * ncode * sizeof(IdxT) + 15) & ~(size_t)15));  // [2][rows_per_block]
-    for (int c = threadIdx.x; c < cpr; c += blockDim.x) {
-        const int f = c * VEC;
+    for (int c = threadIdx.x; c < ntbl; c += blockDim.x) {
+        const int f = c * G;
         tbl[c] = (f / dsub) | ((f % dsub) << 16);
     }
 
@@ -206,21 +211,36 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
         for (int L = threadIdx.x; L < nchunks; L += 256) {
             const int row = (cpr == 1) ? L : (int)__umulhi((unsigned)L, inv_cpr);
             const int c = L - row * cpr;
-            const int me = tbl[c];
-            const int m = me & 0xffff, e = me >> 16;
-            uint64_t code = (uint64_t)cc[row * M + m];
-            if (code >= (uint64_t)K) { bad = true; code = 0; }
-            const float* src = cb + ((int64_t)m * K + (int64_t)code) * dsub + e;
             float* dst = out + (row0 + row) * o_rs + (int64_t)c * VEC;
             const float sc = (SEL && sel_scales) ? scl[cur * rows_per_block + row] : 1.0f;
+            float qv[VEC];
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const int me = tbl[c * NG + gi];
+                const int m = me & 0xffff, e = me >> 16;
+                uint64_t code = (uint64_t)cc[row * M + m];
+                if (code >= (uint64_t)K) { bad = true; code = 0; }
+                const float* src = cb + ((int64_t)m * K + (int64_t)code) * dsub + e;
+                if (G == 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4_u*>(src);
+                    qv[0] = t[0]; qv[1] = t[1]; qv[2] = t[2]; qv[3] = t[3];
+                } else if (G == 2) {
+                    const f32x2 t = *reinterpret_cast<const f32x2_u*>(src);
+                    qv[2 * gi] = t[0]; qv[2 * gi + 1] = t[1];
+                } else {
+                    qv[gi] = *src;
+                }
+            }
+            if (SEL && sel_scales) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) qv[v] = fmul(qv[v], sc);
+            }
             if (VEC == 4) {
                 // streaming store: keep the L2 for the codebook, not for the 1.2 KB/row output
-                f32x4 q = *reinterpret_cast<const f32x4*>(src);
-                if (SEL && sel_scales) { q[0] = fmul(q[0], sc); q[1] = fmul(q[1], sc); q[2] = fmul(q[2], sc); q[3] = fmul(q[3], sc); }
-                __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(dst));
+                const f32x4 q = {qv[0], qv[1], qv[2], qv[3]};
+                __builtin_nontemporal_store(q, reinterpret_cast<f32x4_u*>(dst));
             } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) dst[v] = (SEL && sel_scales) ? fmul(src[v], sc) : src[v];
+                dst[0] = qv[0];
             }
         }
         if (more) stash_codes(cur ^ 1);

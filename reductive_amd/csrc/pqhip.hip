@@ -541,8 +541,11 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     if (n == 0) return PQHIP_OK;
     CodebookDev& cd = cb->dev[slot];
     const int d = (int)cb->d;
-    const bool vec = (cb->dsub % 4 == 0) && (o_rs % 4 == 0) &&
-                     ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
+    // 16-byte output chunks whenever a row is a whole number of them (the stores are dword-aligned
+    // wide stores, so neither the row stride nor the base address matters); a chunk is filled with
+    // one, two or four codebook accesses depending on how sub-vectors line up with it
+    const bool vec = d % 4 == 0;
+    const int gsz = !vec ? 1 : (cb->dsub % 4 == 0) ? 4 : (cb->dsub % 2 == 0) ? 2 : 1;
     const int cpr = vec ? d / 4 : d;
     // rows per block: as many as keep rows*cpr < 2^16 (so that L / cpr == umulhi(L, ceil(2^32 / cpr))
     // exactly: the error term L * (inv * cpr - 2^32) stays below 2^32) and the block's codes within
@@ -568,25 +571,33 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     static const int rec_wgs_per_cu = [] { const char* e = getenv("PQHIP_DEBUG_REC_WGS"); return e ? std::max(1, atoi(e)) : 8; }();
     const unsigned grid =
         (unsigned)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, (int64_t)256 * rec_wgs_per_cu);
-    const size_t lds = (((size_t)cpr * sizeof(int) + 15) & ~(size_t)15) +
+    const size_t lds = (((size_t)cpr * (vec ? 4 / gsz : 1) * sizeof(int) + 15) & ~(size_t)15) +
                        (((size_t)2 * rows_per_block * cb->M * code_bytes + 15) & ~(size_t)15) +
                        (sel_rows ? (size_t)2 * rows_per_block * sizeof(float) : 0);
-#define LAUNCH_REC(IDX, V)                                                                        \
+#define LAUNCH_REC2(IDX, V, GG)                                                                   \
     do {                                                                                          \
         if (sel_rows)                                                                             \
-            hipLaunchKernelGGL((k_reconstruct<IDX, V, true>), dim3(grid), dim3(256), lds, st,     \
+            hipLaunchKernelGGL((k_reconstruct<IDX, V, true, GG>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
                                (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, cd.err,        \
                                sel_rows, n_codes, sel_scales);                                    \
         else                                                                                      \
-            hipLaunchKernelGGL((k_reconstruct<IDX, V, false>), dim3(grid), dim3(256), lds, st,    \
+            hipLaunchKernelGGL((k_reconstruct<IDX, V, false, GG>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
                                (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, cd.err,        \
                                (const int64_t*)nullptr, (int64_t)0, (const float*)nullptr);       \
     } while (0)
-    if (code_bytes == 1) { if (vec) LAUNCH_REC(uint8_t, 4); else LAUNCH_REC(uint8_t, 1); }
-    else if (code_bytes == 4) { if (vec) LAUNCH_REC(uint32_t, 4); else LAUNCH_REC(uint32_t, 1); }
+#define LAUNCH_REC(IDX)                                                                           \
+    do {                                                                                          \
+        if (!vec) LAUNCH_REC2(IDX, 1, 1);                                                         \
+        else if (gsz == 4) LAUNCH_REC2(IDX, 4, 4);                                                \
+        else if (gsz == 2) LAUNCH_REC2(IDX, 4, 2);                                                \
+        else LAUNCH_REC2(IDX, 4, 1);                                                              \
+    } while (0)
+    if (code_bytes == 1) LAUNCH_REC(uint8_t);
+    else if (code_bytes == 4) LAUNCH_REC(uint32_t);
     else return PQHIP_EUNSUPPORTED;
+#undef LAUNCH_REC2
 #undef LAUNCH_REC
     HIPCHK(hipGetLastError());
     return PQHIP_OK;
