@@ -349,6 +349,57 @@ def test_device_resident_and_properties_at_scale(ra):
         pq2.reconstruct_batch_device(bad, check=True)
 
 
+def test_full_size_headline_batch_every_code(ra):
+    """BASELINE configs[1] at full size: all 150 M codes of the 10 M x 300 batch against the oracle
+    (sharded over the host's cores), plus decode -> encode idempotence and the gather checksum on all rows."""
+    import torch
+    M, K, dsub = 15, 256, 20
+    n = 10_000_000
+    q = synth.normalish(43, (M, K, dsub))
+    pq = _pq(ra, q)
+    g = torch.Generator(device="cuda").manual_seed(42)
+    x = torch.empty((n, M * dsub), device="cuda", dtype=torch.float32)
+    for r0 in range(0, n, 1 << 20):
+        x[r0:r0 + (1 << 20)].normal_(generator=g)
+    codes = pq.quantize_batch_device(x)
+    rec = pq.reconstruct_batch_device(codes, check=True)
+    assert torch.equal(pq.quantize_batch_device(rec), codes)
+    qt = torch.from_numpy(q).cuda()
+    s_ref = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for m in range(M):
+        s_ref += qt[m].double().sum(1)[codes[:, m].long()]
+    assert torch.allclose(rec.double().sum(1), s_ref, rtol=0, atol=1e-9)
+    del rec, s_ref
+    got = codes.cpu().numpy()
+    cores = os.cpu_count() or 8
+    step = 2_500_000                                   # 3 GB of host memory per slice
+    for r0 in range(0, n, step):
+        want = orc.quantize_batch(q, x[r0:r0 + step].cpu().numpy(), n_threads=cores)
+        assert got[r0:r0 + step].tobytes() == want.tobytes(), r0
+
+
+def test_opq_one_million_rows_every_code_and_reconstruction(ra):
+    """BASELINE configs[2] shape at 1 M rows: rotation + encode codes and the un-rotated
+    reconstructions, every element, against the oracle on all host cores."""
+    import torch
+    M, K, dsub = 15, 256, 20
+    d, n = M * dsub, 1_000_000
+    q = synth.normalish(43, (M, K, dsub))
+    P = synth.orthonormal(44, d)
+    pq = _pq(ra, q, P)
+    g = torch.Generator(device="cuda").manual_seed(46)
+    x = torch.randn((n, d), device="cuda", dtype=torch.float32, generator=g)
+    codes = pq.quantize_batch_device(x)
+    rec = pq.reconstruct_batch_device(codes, check=True)
+    cores = os.cpu_count() or 8
+    want = orc.quantize_batch(q, x.cpu().numpy(), projection=P, n_threads=cores)
+    assert codes.cpu().numpy().tobytes() == want.tobytes()
+    ref = orc.reconstruct_batch(q, want[:100_000], projection=P)
+    got = rec[:100_000].cpu().numpy()
+    assert np.abs(got - ref).max() <= REL_TOL * np.abs(ref).max()
+    assert got.tobytes() == ref.tobytes()
+
+
 def test_statistical_roundtrip_loss(ra, kats):
     """pq.rs:431-440 analogue: a trained 7-bit quantizer on U[0,1) 256x20 reconstructs with mean
     Euclidean loss < 0.08 (training itself is out of scope: a few Lloyd steps in numpy)."""
