@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="encode")
     ap.add_argument("--d", type=int, default=300)
     ap.add_argument("--m", type=int, default=15)
-    ap.add_argument("--k", type=int, default=256, help="centroids per subquantizer (<= 256 for u8 codes)")
+    ap.add_argument("--k", type=int, default=256, help="centroids per subquantizer (u8 codes up to 256, 32-bit codes beyond)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 anchor kernel, 2 MFMA kernel")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,7 +149,7 @@ def main():
             src = torch.empty((rows, D), device=dev, dtype=torch.float32)
             for r0 in range(0, rows, 1 << 20):    # N(0,1) like benches/pq.rs:9, generated in HBM
                 src[r0:r0 + (1 << 20)].normal_(generator=g)
-            dst = torch.empty((rows, M), device=dev, dtype=torch.uint8)
+            dst = torch.empty((rows, M), device=dev, dtype=torch.uint8 if K <= 256 else torch.int32)
 
             def step():
                 pq.quantize_batch_device(src, out=dst)

@@ -22,14 +22,26 @@ template <int KIND, int T, int DP>
 static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st)
 {
     const unsigned pad = debug_lds_pad();
+    if (code_bytes == 8) {   // key mode of grouped codebooks: default kernel, 8 tiles per group
+        if constexpr (KIND == 2 && T == 8) {
+            if (vec) hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, true, unsigned long long>), grid, dim3(256), pad, st, a);
+            else hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, false, unsigned long long>), grid, dim3(256), pad, st, a);
+            return true;
+        } else {
+            return false;
+        }
+    }
     if (code_bytes == 4) {
-        if (KIND != 2) return false;
-        if (vec) hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, true, uint32_t>), grid, dim3(256), pad, st, a);
-        else hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, false, uint32_t>), grid, dim3(256), pad, st, a);
-        return true;
+        if constexpr (KIND == 2) {
+            if (vec) hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, true, uint32_t>), grid, dim3(256), pad, st, a);
+            else hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, false, uint32_t>), grid, dim3(256), pad, st, a);
+            return true;
+        } else {
+            return false;
+        }
     }
     if (code_bytes != 1) return false;
-    if (KIND == 0) {
+    if constexpr (KIND == 0) {
         if (vec) hipLaunchKernelGGL((k_encode_mfma<T, DP, true, uint8_t>), grid, dim3(256), pad, st, a);
         else hipLaunchKernelGGL((k_encode_mfma<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
     } else {

@@ -106,6 +106,24 @@ __global__ void k_rotate_scalar(const float* __restrict__ x, int64_t n, int64_t 
     }
 }
 
+// Grouped codebooks (K > 256): codes[row][m] = index part of the minimum over the groups of the
+// 64-bit keys {ordered distance, global index} the MFMA kernel left per (row, virtual m).
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_merge_keys(const unsigned long long* __restrict__ keys, int64_t n,
+                                                    int M, int groups, IdxT* __restrict__ codes, int64_t o_rs)
+{
+    const int64_t total = n * M;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / M;
+        const int m = (int)(idx - row * M);
+        const unsigned long long* k = keys + (row * M + m) * groups;
+        unsigned long long best = k[0];
+        for (int g = 1; g < groups; ++g) best = (k[g] < best) ? k[g] : best;
+        codes[row * o_rs + m] = (IdxT)(unsigned)best;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Reconstruct gather  (primitives.rs:137-147, 169-172):
 //   out[row, m*dsub + e] = cb[m][codes[row, m]][e]      -- a pure copy, bit exact.

@@ -35,7 +35,22 @@ struct EncodeArgs {
     int rows_per_item;   // multiple of 32
     int64_t n_chunks;    // ceil(n / rows_per_item)
     int64_t chunks_per_xcd;  // ceil(n_chunks / 8)
+    // K > 256 ("grouped" codebooks): every subquantizer is presented as `groups` virtual ones of
+    // 256 centroids each (M above is then M_real * groups, K the real K); the kernel writes one
+    // 64-bit key {ordered distance, global centroid index} per (row, virtual m) and k_merge_keys
+    // takes the minimum over the groups.  groups == 1: plain codes.
+    int groups;
 };
+
+// Order-preserving map of an f32 distance onto u32 under ordered-float's total order
+// (kmeans.rs:149-156): NaN greatest, -0 == +0.  Smaller key <=> smaller distance.
+__device__ __forceinline__ unsigned ord_key(float d)
+{
+    if (d != d) return 0xffffffffu;
+    if (d == 0.f) return 0x80000000u;
+    const unsigned u = (unsigned)__float_as_int(d);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
 
 // Exact-by-construction tile evaluation used when a tile holds NaN/Inf/huge values or a negative
 // minimum: lanes of the lower half scan all K centroids with the literal three-operation distance
@@ -66,6 +81,30 @@ template <typename IdxT>
 __device__ __forceinline__ void encode_tile_slow(const EncodeArgs& a, int m, int64_t row, bool valid)
 {
     encode_tile_slow_v<IdxT>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, m, row, valid);
+}
+
+// Grouped codebooks: the exact scan runs over ALL K centroids of the real subquantizer and leaves
+// its key in this virtual subquantizer's slot -- never worse than the group's own best, and on a
+// tie the full scan holds the lower index, so the merged minimum is the reference's answer.
+__device__ __noinline__ void encode_tile_slow_key_v(const float* x, int64_t x_rs, void* out, int64_t o_rs,
+                                                    const float* cb, const float* cc, int K, int dsub,
+                                                    int k_pad, int groups, int mv, int64_t row, bool valid)
+{
+    if (!valid || (threadIdx.x & 32)) return;
+    const int m = mv / groups;
+    const float* xs = x + row * x_rs + (int64_t)m * dsub;
+    const float* cbm = cb + (int64_t)m * K * dsub;
+    const float* ccm = cc + (int64_t)m * k_pad;
+    const float xx = norm_unrolled_global(xs, dsub);
+    int best = 0;
+    float bestd = 0.f;
+    for (int j = 0; j < K; ++j) {
+        const float dp = chain_dot_global(xs, 1, cbm + (int64_t)j * dsub, 1, dsub);
+        const float d = fsub(fadd(xx, ccm[j]), fadd(dp, dp));
+        if (j == 0 || of_less(d, bestd)) { bestd = d; best = j; }
+    }
+    reinterpret_cast<unsigned long long*>(out)[row * o_rs + mv] =
+        ((unsigned long long)ord_key(bestd) << 32) | (unsigned long long)(unsigned)best;
 }
 
 // ---------------------------------------------------------------------------------------------

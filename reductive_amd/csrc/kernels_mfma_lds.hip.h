@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
     if (!wg_active || row_begin >= a.n) return;
     int64_t row_end = row_begin + a.rows_per_item;
     if (row_end > a.n) row_end = a.n;
-    const float* xcol = a.x + (int64_t)m * a.dsub;
+    // IdxT == u64 is the key mode of grouped codebooks (K > 256): m is a virtual subquantizer
+    constexpr bool KEYS = sizeof(IdxT) == 8;
+    const int m_real = KEYS ? m / a.groups : m;
+    const float* xcol = a.x + (int64_t)m_real * a.dsub;
 
     // x tile: lane j reads the DP floats of its row's sub-vector.  Rows past the end are clamped
     // to the last row (their result is never stored).
@@ -199,9 +202,19 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
         const int64_t row = row0 + j;
         const bool valid = row < a.n;
         if (__builtin_amdgcn_ballot_w64(!(xx < kBigNorm) || neg) != 0ull) {
-            encode_tile_slow<IdxT>(a, m, row, valid);
+            if (KEYS)
+                encode_tile_slow_key_v(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, a.groups, m, row, valid);
+            else
+                encode_tile_slow<IdxT>(a, m, row, valid);
         } else if (h == 0 && valid) {
-            reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
+            if (KEYS) {
+                const float bd = (od < best) ? od : best;   // finite and >= 0 here
+                const unsigned gidx = (unsigned)bidx + 256u * (unsigned)(m - m_real * a.groups);
+                reinterpret_cast<unsigned long long*>(a.out)[row * a.o_rs + m] =
+                    ((unsigned long long)ord_key(bd) << 32) | (unsigned long long)gidx;
+            } else {
+                reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
+            }
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = bop_n[s];

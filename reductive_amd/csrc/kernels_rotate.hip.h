@@ -386,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void k_rotate_pblock5(const float* __restri
     float* xs = xs_all + (size_t)wave * 2 * 32 * XS;
     const float* plane = pl + 4 * j + 2 * h;     // + q * 256 floats per group; + 128: second column tile
     const int nslab = kpad / 32;
+    const int tail_groups = (d - 32 * (nslab - 1) + 3) / 4;  // 4-k groups with real k in the last slab
     constexpr int SB = kKC / 32;                 // slabs per rule-2 block
     const int lr = lane >> 3, lc = lane & 7;     // staging role: rows lr + 8 i, 16-byte piece lc
 
@@ -434,8 +435,7 @@ __global__ __launch_bounds__(512, 2) void k_rotate_pblock5(const float* __restri
                 if (more) fetch(slab + 1);
                 const float* arow = xs + ((size_t)buf * 32 + j) * XS + 2 * h;
                 const float* pq = plane + slab * 8 * 256;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                auto group = [&](int u) {        // 4 k of both column tiles
                     const f32x2 a = *reinterpret_cast<const f32x2*>(arow + 4 * u);
                     const f32x2 b0 = *reinterpret_cast<const f32x2*>(pq + u * 256);
                     const f32x2 b1 = *reinterpret_cast<const f32x2*>(pq + u * 256 + 128);
@@ -443,6 +443,16 @@ __global__ __launch_bounds__(512, 2) void k_rotate_pblock5(const float* __restri
                     c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b1[0], c1, 0, 0, 0);
                     c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b0[1], c0, 0, 0, 0);
                     c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b1[1], c1, 0, 0, 0);
+                };
+                if (more || tail_groups == 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) group(u);
+                } else {
+                    // last slab of a k that is not a multiple of 32 (d = 300: 12 of 32): only the
+                    // groups that hold real k (zero k-padding is exact, but it is not free)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (u < tail_groups) group(u);
                 }
                 if (more) stash(buf ^ 1);
             }

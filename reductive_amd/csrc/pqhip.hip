@@ -73,6 +73,8 @@ struct CodebookDev {
     float* P = nullptr;      // [d][d]   x.dot(P)
     float* PT = nullptr;     // [d][d]   r.dot(P^T)
     int* err = nullptr;      // bit 0: code >= K seen by reconstruct
+    unsigned long long* keys = nullptr;  // grouped codebooks (K > 256): [rows][M * groups] partial minima
+    int64_t keys_rows = 0;
     float* scratch = nullptr;
     int64_t scratch_rows = 0;
     hipEvent_t scratch_done = nullptr;
@@ -90,6 +92,7 @@ struct pqhip_codebook {
     bool has_proj = false;
     // MFMA encode geometry (0 = shape not covered, anchor kernel is used)
     int T = 0, DP = 0, k_pad = 0;
+    int groups = 1;         // K > 256: groups of 256 centroids (8 tiles each) merged through 64-bit keys
     bool norms_ok = false;  // all ||c||^2 finite and < 2^100
     int variant = 0;        // 0 auto, 1 anchor, 2 mfma
     std::vector<CodebookDev> dev;
@@ -133,15 +136,61 @@ void free_staging(Staging& s)
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// K > 256 on the MFMA path: every subquantizer is presented to the default kernel as `groups`
+// virtual subquantizers of 256 centroids; the kernel leaves a 64-bit key {ordered distance, global
+// index} per (row, virtual m) and k_merge_keys reduces them to u32 codes.  Rows are chunked so that
+// the key buffer stays <= 1 GiB; the buffer is shared by all streams using this codebook on the
+// device, ordered through the same event as the OPQ scratch.
+int32_t encode_grouped_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
+                           void* d_codes, int64_t o_rs, hipStream_t st)
+{
+    CodebookDev& cd = cb->dev[slot];
+    const int64_t Mv = cb->M * cb->groups;
+    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(4096, (1ll << 30) / (Mv * 8)));
+    if (cd.keys_rows < chunk) {
+        std::lock_guard<std::mutex> g(cb->mu);
+        if (cd.keys_rows < chunk) {
+            if (cd.keys) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(cd.keys); cd.keys = nullptr; cd.keys_rows = 0; }
+            HIPCHK(hipMalloc((void**)&cd.keys, (size_t)chunk * Mv * sizeof(unsigned long long)));
+            cd.keys_rows = chunk;
+        }
+    }
+    HIPCHK(hipStreamWaitEvent(st, cd.scratch_done, 0));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t rows = std::min<int64_t>(chunk, n - r0);
+        EncodeArgs a;
+        a.x = d_x + r0 * x_rs; a.n = rows; a.x_rs = x_rs; a.out = cd.keys; a.o_rs = Mv;
+        a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
+        a.M = (int)Mv; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
+        a.groups = cb->groups;
+        int64_t rpi = round_up((rows * Mv + 4 * 4096 - 1) / (4 * 4096), 32);
+        rpi = std::max<int64_t>(32, std::min<int64_t>(1024, rpi));
+        a.rows_per_item = (int)rpi;
+        a.n_chunks = (rows + 4 * rpi - 1) / (4 * rpi);
+        a.chunks_per_xcd = (a.n_chunks + 7) / 8;
+        const dim3 grid((unsigned)(a.chunks_per_xcd * Mv * 8));
+        if (!launch_encode_mfma(2, 8, cb->DP, cb->DP == cb->dsub, 8, a, grid, st)) return PQHIP_EUNSUPPORTED;
+        const unsigned mg = (unsigned)std::min<int64_t>((rows * cb->M + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL((k_merge_keys<uint32_t>), dim3(mg), dim3(256), 0, st, cd.keys, rows, (int)cb->M, cb->groups,
+                           (uint32_t*)d_codes + r0 * o_rs, o_rs);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(cd.scratch_done, st));
+    cb->last_kernel = "k_encode_mfma_lds3<grouped>";
+    return PQHIP_OK;
+}
+
 // PQ encode of device-resident, already rotated rows.
 int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
                          void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st)
 {
     if (n == 0) return PQHIP_OK;
     CodebookDev& cd = cb->dev[slot];
+    if (cb->groups > 1 && cb->variant != 1 && cb->norms_ok && code_bytes == 4)
+        return encode_grouped_dev(cb, slot, d_x, n, x_rs, d_codes, o_rs, st);
     // MFMA kernels: u8 codes from every variant, u32 codes (k-means assignments, wide index types)
-    // from the default variant; K <= 256 either way
-    const bool mfma_possible = cb->T != 0 && cb->norms_ok &&
+    // from the default variant; K <= 256 here (larger K: encode_grouped_dev above, or the anchor)
+    const bool mfma_possible = cb->groups == 1 && cb->T != 0 && cb->norms_ok &&
                                (code_bytes == 1 || (code_bytes == 4 && (cb->variant == 0 || cb->variant == 4)));
     bool use_mfma = mfma_possible;
     if (cb->variant == 1) use_mfma = false;
@@ -152,6 +201,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         a.x = d_x; a.n = n; a.x_rs = x_rs; a.out = d_codes; a.o_rs = o_rs;
         a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
         a.M = (int)cb->M; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
+        a.groups = 1;
         // kernel kind: 0 VALU argmin, 2 LDS argmin + LDS A fragments (variant 3, the retired
         // register-resident LDS-argmin kernel, is an alias of the default)
         // auto: for sub-vectors of <= 4 floats the per-distance work outweighs the MFMA chain and the
@@ -286,9 +336,10 @@ int32_t prepare_codebook_dev(pqhip_codebook* cb, int slot, hipStream_t st, bool*
     }
     if (cb->T) {
         const int S = cb->DP / 2;
-        const int64_t total = M * cb->T * S * 64;
+        const int tiles = cb->T * cb->groups;  // grouped codebooks: [M][groups * 8][S][64]
+        const int64_t total = M * tiles * S * 64;
         hipLaunchKernelGGL(k_build_frags, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           cd.cb, (int)M, (int)K, (int)dsub, cb->T, S, cd.frags);
+                           cd.cb, (int)M, (int)K, (int)dsub, tiles, S, cd.frags);
     }
     HIPCHK(hipGetLastError());
     int bad = 0;
@@ -319,15 +370,20 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
     cb->has_proj = projection != nullptr;
     // MFMA geometry: K <= 256 padded to {1,2,4,8} tiles of 32; dsub <= 32 padded to an even
     // number of k (one MFMA consumes two); A fragments must fit (T * DP/2 <= 128).
-    int T = 0, DP = 0;
+    int T = 0, DP = 0, groups = 1;
     if (K <= 256 && dsub <= 32) {
         const int tiles = (int)((K + 31) / 32);
         T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
         DP = (int)round_up(dsub, 2);
         if (T * (DP / 2) > 128) { T = 0; DP = 0; }
+    } else if (K <= 65536 && dsub <= 32) {
+        // grouped: ceil(K / 256) virtual subquantizers of 8 tiles each per real one
+        T = 8;
+        DP = (int)round_up(dsub, 2);
+        groups = (int)((K + 255) / 256);
     }
-    cb->T = T; cb->DP = DP;
-    cb->k_pad = T ? T * 32 : (int)round_up(K, 32);
+    cb->T = T; cb->DP = DP; cb->groups = groups;
+    cb->k_pad = T ? T * 32 * groups : (int)round_up(K, 32);
     const int S = DP / 2;
 
     std::vector<float> PT;
@@ -351,7 +407,7 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
         HIPCHK(hipMalloc((void**)&cd.err, 2 * sizeof(int)));
         HIPCHK(hipMemsetAsync(cd.err, 0, 2 * sizeof(int), st));
         HIPCHK(hipEventCreateWithFlags(&cd.scratch_done, hipEventDisableTiming));
-        if (T) HIPCHK(hipMalloc((void**)&cd.frags, (size_t)(M * T * S * 64) * sizeof(float)));
+        if (T) HIPCHK(hipMalloc((void**)&cd.frags, (size_t)(M * groups * T * S * 64) * sizeof(float)));
         if (projection) {
             const size_t pb = (size_t)cb->d * cb->d * sizeof(float);
             HIPCHK(hipMalloc((void**)&cd.P, pb));
@@ -827,6 +883,7 @@ void pqhip_codebook_destroy(pqhip_codebook* cb)
         if (cd.PT) (void)hipFree(cd.PT);
         if (cd.err) (void)hipFree(cd.err);
         if (cd.scratch) (void)hipFree(cd.scratch);
+        if (cd.keys) (void)hipFree(cd.keys);
         if (cd.scratch_done) (void)hipEventDestroy(cd.scratch_done);
     }
     delete cb;

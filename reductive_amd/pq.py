@@ -421,7 +421,7 @@ class Pq:
         return ctx.devices.index(dev)
 
     def quantize_batch_device(self, x, out=None, stream=None):
-        """x: CUDA float32 tensor [n, d] (unit column stride) -> uint8 codes tensor [n, M].
+        """x: CUDA float32 tensor [n, d] (unit column stride) -> codes tensor [n, M] (uint8; int32 when K > 256).
         Asynchronous on torch's current stream unless `stream` (a raw hipStream_t int) is given."""
         import torch
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
@@ -430,17 +430,20 @@ class Pq:
         if x.stride(1) != 1:
             x = x.contiguous()
         if out is None:
-            out = torch.empty((x.shape[0], self.quantized_len()), dtype=torch.uint8, device=x.device)
+            # u8 codes, or 32-bit codes (int32 tensor, values < 2^31) when K > 256
+            dt = torch.uint8 if self.n_quantizer_centroids() <= 256 else torch.int32
+            out = torch.empty((x.shape[0], self.quantized_len()), dtype=dt, device=x.device)
         if tuple(out.shape) != (x.shape[0], self.quantized_len()):
             raise PanicError("Quantized matrix has incorrect shape, expected: (%d, %d), got: (%d, %d)"
                              % (x.shape[0], self.quantized_len(), out.shape[0], out.shape[1]))
-        assert out.is_cuda and out.dtype == torch.uint8 and out.stride(1) == 1
+        assert out.is_cuda and out.dtype in (torch.uint8, torch.int32) and out.stride(1) == 1
+        code_bytes = 1 if out.dtype == torch.uint8 else 4
         cb = self._cb()
         if stream is None:
             stream = torch.cuda.current_stream(x.device).cuda_stream
         rc = _lib.lib().pqhip_quantize_batch_f32_dev(cb, self._slot_for(x), x.data_ptr(), x.shape[0],
                                                     x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1]),
-                                                    out.data_ptr(), 1,
+                                                    out.data_ptr(), code_bytes,
                                                     out.stride(0) if out.shape[0] > 1 else max(out.stride(0), out.shape[1]),
                                                     ctypes.c_void_p(stream))
         if rc == _lib.EINDEX_WIDTH:

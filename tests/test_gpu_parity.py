@@ -244,6 +244,42 @@ def test_wide_and_narrow_rows(ra, M, K, dsub):
     assert pq.reconstruct_batch(codes).tobytes() == orc.reconstruct_batch(q, codes).tobytes()
 
 
+@pytest.mark.parametrize("shape", [(3000, 3, 1000, 16), (1500, 2, 4096, 8), (700, 1, 257, 20), (900, 4, 300, 6),
+                                   (400, 2, 513, 3), (2500, 15, 1024, 20)])
+def test_more_than_256_centroids_on_the_matrix_path(ra, shape):
+    """K > 256 (u16/u32 codes; k-means with many centroids): groups of 256 centroids through the
+    default kernel, merged by 64-bit {distance, index} keys -- codes equal the oracle's, including
+    ties across groups, NaN/Inf/huge rows and exact hits (negative-distance slow path)."""
+    n, M, K, dsub = shape
+    q = synth.normalish(1300 + K, (M, K, dsub))
+    x = synth.normalish(1301 + K, (n, M * dsub))
+    q[0, K - 1] = q[0, 5]                      # duplicate in the last group: index 5 must win
+    q[M - 1, 300 % K] = q[M - 1, 2]
+    x[:40, :dsub] = q[0, 5]                    # rows sitting exactly on the duplicated centroid
+    x[40:80, (M - 1) * dsub:] = q[M - 1, 2]
+    x[100, 0] = np.nan
+    x[101, 1 % (M * dsub)] = np.inf
+    x[102] *= np.float32(1e19)
+    x[103] *= np.float32(3e19)
+    want = orc.quantize_batch(q, x, dtype=np.uint32)
+    assert (want[:40, 0] == 5).all()
+    pq = _pq(ra, q)
+    for dt in (np.uint16, np.uint32, np.uint64):
+        got = pq.quantize_batch(x, dtype=dt)
+        assert got.astype(np.uint32).tobytes() == want.tobytes(), dt
+    assert pq.last_encode_kernel() == "k_encode_mfma_lds3<grouped>"
+    assert _pq(ra, q, variant=1).quantize_batch(x, dtype=np.uint32).tobytes() == want.tobytes()
+    # OPQ in front of it, and the k-means step on top of it
+    if M * dsub <= 64:
+        P = synth.orthonormal(1302 + K, M * dsub)
+        assert _pq(ra, q, P).quantize_batch(x, dtype=np.uint32).tobytes() == \
+            orc.quantize_batch(q, x, projection=P, dtype=np.uint32).tobytes()
+    xs = synth.normalish(1303 + K, (n, M * dsub))
+    wq, wl = orc.kmeans_iterations(q, xs, n_iterations=2, n_threads=8)
+    gq, gl = ra.kmeans_iterations(q, xs, n_iterations=2)
+    assert gq.tobytes() == wq.tobytes() and gl.tobytes() == wl.tobytes()
+
+
 def test_strided_host_buffers(ra):
     M, K, dsub = 3, 32, 4
     q = synth.normalish(71, (M, K, dsub))
