@@ -167,6 +167,23 @@ __device__ __forceinline__ void load_row_floats(const float* __restrict__ p, flo
     for (int e = CNT; e < N; ++e) v[e] = 0.f;
 }
 
+// Same with a run-time (wave-uniform) count: used by the wide sub-vector instantiations, whose
+// padded length is a multiple of 8 and whose real length is any value below it.
+template <int N>
+__device__ __forceinline__ void load_row_floats_rt(const float* __restrict__ p, int cnt, float (&v)[N])
+{
+#pragma unroll
+    for (int e = 0; e < N; e += 4) {
+        if (e + 4 <= cnt) {
+            const f32x4 q = *reinterpret_cast<const f32x4_u*>(p + e);
+            v[e] = q[0]; v[e + 1] = q[1]; v[e + 2] = q[2]; v[e + 3] = q[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[e + i] = (e + i < cnt) ? p[e + i] : 0.f;
+        }
+    }
+}
+
 // One sequential fmaf chain with restarts every kKC (rule 2), global operands with strides.
 __device__ inline float chain_dot_global(const float* __restrict__ a, int64_t as,
                                          const float* __restrict__ b, int64_t bs, int n)

@@ -7,7 +7,8 @@
 
 namespace pqhip {
 // KIND 0: k_encode_mfma (VALU argmin epilogue); KIND 2: k_encode_mfma_lds3 (LDS-atomic argmin,
-// A fragments in LDS, 3 waves/SIMD).  DPSET 0: DP in {4, 8, .., 32}; DPSET 1: DP in {2, 6, .., 30}.
+// A fragments in LDS, 3 waves/SIMD).  DPSET 0: DP in {4, 8, .., 32}; DPSET 1: DP in {2, 6, .., 30};
+// DPSET 2 (KIND 2 only): wide sub-vectors, DP in {40, 48, 56, 64}.
 // Returns false when (T, DP, code_bytes) has no instantiation: u8 codes for both kinds, u32 codes
 // (k-means assignment step / wide index types) for KIND 2 only.
 template <int KIND, int T, int DPSET>
@@ -16,6 +17,10 @@ bool launch_encode_mfma_t(int DP, bool vec, int code_bytes, const EncodeArgs& a,
 #define PQHIP_DECL_LAUNCH(KIND, T)                                                                              \
     extern template bool launch_encode_mfma_t<KIND, T, 0>(int, bool, int, const EncodeArgs&, dim3, hipStream_t); \
     extern template bool launch_encode_mfma_t<KIND, T, 1>(int, bool, int, const EncodeArgs&, dim3, hipStream_t);
+#define PQHIP_DECL_WIDE(T) \
+    extern template bool launch_encode_mfma_t<2, T, 2>(int, bool, int, const EncodeArgs&, dim3, hipStream_t);
+PQHIP_DECL_WIDE(1) PQHIP_DECL_WIDE(2) PQHIP_DECL_WIDE(4) PQHIP_DECL_WIDE(8)
+#undef PQHIP_DECL_WIDE
 PQHIP_DECL_LAUNCH(0, 1) PQHIP_DECL_LAUNCH(0, 2) PQHIP_DECL_LAUNCH(0, 4) PQHIP_DECL_LAUNCH(0, 8)
 PQHIP_DECL_LAUNCH(2, 1) PQHIP_DECL_LAUNCH(2, 2) PQHIP_DECL_LAUNCH(2, 4) PQHIP_DECL_LAUNCH(2, 8)
 #undef PQHIP_DECL_LAUNCH
@@ -23,6 +28,11 @@ PQHIP_DECL_LAUNCH(2, 1) PQHIP_DECL_LAUNCH(2, 2) PQHIP_DECL_LAUNCH(2, 4) PQHIP_DE
 inline bool launch_encode_mfma(int kind, int T, int DP, bool vec, int code_bytes, const EncodeArgs& a,
                                dim3 grid, hipStream_t st)
 {
+#define PQHIP_WIDE(TT) \
+    if (kind == 2 && T == TT && DP > 32) return launch_encode_mfma_t<2, TT, 2>(DP, vec, code_bytes, a, grid, st);
+    PQHIP_WIDE(1) PQHIP_WIDE(2) PQHIP_WIDE(4) PQHIP_WIDE(8)
+#undef PQHIP_WIDE
+    if (DP > 32) return false;
 #define PQHIP_CASE(KIND, TT)                                                                              \
     if (kind == KIND && T == TT)                                                                          \
         return (DP % 4 == 0) ? launch_encode_mfma_t<KIND, TT, 0>(DP, vec, code_bytes, a, grid, st)        \

@@ -1,6 +1,7 @@
 // encode_launch.hip -- compiled once per (PQ_KIND, PQ_T, PQ_DPSET) by the Makefile.
 // PQ_KIND 0: VALU-argmin kernel, 2: LDS-argmin kernel with LDS-resident fragments (the default).
-// PQ_DPSET 0: padded sub-dimension DP = 0 (mod 4), 1: DP = 2 (mod 4).
+// PQ_DPSET 0: padded sub-dimension DP = 0 (mod 4), 1: DP = 2 (mod 4), 2: wide sub-vectors DP in
+// {40, 48, 56, 64} (default kernel only).
 #include "encode_launch.h"
 #include <cstdlib>
 #include "kernels_mfma_lds.hip.h"
@@ -54,7 +55,7 @@ static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid,
 template <int KIND, int T, int DPSET>
 bool launch_encode_mfma_t(int DP, bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st)
 {
-    if (DPSET == 0) {
+    if constexpr (DPSET == 0) {
         switch (DP) {
         case 4: return launch_vec<KIND, T, 4>(vec, code_bytes, a, grid, st);
         case 8: return launch_vec<KIND, T, 8>(vec, code_bytes, a, grid, st);
@@ -65,6 +66,18 @@ bool launch_encode_mfma_t(int DP, bool vec, int code_bytes, const EncodeArgs& a,
         case 28: return launch_vec<KIND, T, 28>(vec, code_bytes, a, grid, st);
         case 32: return launch_vec<KIND, T, 32>(vec, code_bytes, a, grid, st);
         default: return false;
+        }
+    } else if constexpr (DPSET == 2) {
+        if constexpr (KIND == 2) {
+            switch (DP) {
+            case 40: return launch_vec<KIND, T, 40>(vec, code_bytes, a, grid, st);
+            case 48: return launch_vec<KIND, T, 48>(vec, code_bytes, a, grid, st);
+            case 56: return launch_vec<KIND, T, 56>(vec, code_bytes, a, grid, st);
+            case 64: return launch_vec<KIND, T, 64>(vec, code_bytes, a, grid, st);
+            default: return false;
+            }
+        } else {
+            return false;
         }
     } else {
         switch (DP) {

@@ -28,9 +28,11 @@ namespace pqhip {
 // tile's keys; ||c||^2 of the next tile is read behind the atomics, during the chain.
 // Occupancy experiment on MI355X (same kernel body, 1 vs 2 waves/SIMD): 51.8 % -> 66.4 % of MFMA
 // peak -- the loop is latency-bound per wave, so the third wave is worth more than the registers.
+// Wide sub-vectors (32 < dsub <= 64, DP in {40, 48, 56, 64}) use the same body with one wave per
+// SIMD: their chains are 20..32 MFMAs long, so there is little left to hide.
 // ---------------------------------------------------------------------------------------------
 template <int T, int DP, bool VEC, typename IdxT>
-__global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
+__global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(EncodeArgs a)
 {
     constexpr int S = DP / 2;
     __shared__ __attribute__((aligned(16))) float afrag_s[T][S][64];
@@ -77,9 +79,11 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
     auto load_tile = [&](f32x2 (&v2)[DP / 2], int64_t tile_row0) {
         const int left = (int)((a.n - tile_row0 < 32) ? a.n - tile_row0 : 32);  // wave-uniform
         const float* p = (j < left) ? xcol + (tile_row0 + j) * a.x_rs : plast;
-        // VEC: all DP floats are real (dsub == DP); otherwise dsub == DP - 1 and the last one is padding
+        // VEC: all DP floats are real (dsub == DP).  Otherwise: DP <= 32 -> dsub == DP - 1 and the
+        // last one is padding; DP > 32 (wide sub-vectors, DP a multiple of 8) -> run-time dsub < DP
         float v[DP];
-        load_row_floats<VEC ? DP : DP - 1, DP>(p, v);
+        if (VEC || DP <= 32) load_row_floats<VEC ? DP : DP - 1, DP>(p, v);
+        else load_row_floats_rt<DP>(p, a.dsub, v);
 #pragma unroll
         for (int e = 0; e < DP; e += 2) v2[e / 2] = (f32x2){v[e], v[e + 1]};
     };
@@ -88,11 +92,16 @@ __global__ __launch_bounds__(256, 3) void k_encode_mfma_lds3(EncodeArgs a)
         // if-converts and executes BOTH norm variants for every tile (~100 VALU)
         if (VEC) {
             xx = norm_unrolled_packed<DP>(v2);
-        } else {
+        } else if (DP <= 32) {
             float v[DP - 1];
 #pragma unroll
             for (int e = 0; e < DP - 1; ++e) v[e] = v2[e / 2][e & 1];
             xx = norm_unrolled_static<DP - 1>(v);
+        } else {
+            float v[DP];
+#pragma unroll
+            for (int e = 0; e < DP; ++e) v[e] = v2[e / 2][e & 1];
+            xx = norm_unrolled_padded<DP>(v, a.dsub);
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = h ? v2[s][1] : v2[s][0];

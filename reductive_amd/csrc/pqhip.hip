@@ -207,6 +207,9 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         // auto: for sub-vectors of <= 4 floats the per-distance work outweighs the MFMA chain and the
         // LDS pipe (one atomic per 64 distances) becomes the bound: the VALU-argmin kernel is 10-15 % faster
         const bool tiny = cb->variant == 0 && cb->DP <= 4 && code_bytes == 1;
+        // the VALU-argmin kernel keeps all T * DP/2 fragments in registers: small codebooks only
+        const bool kind0_fits = cb->DP <= 32 && cb->T * (cb->DP / 2) <= 128 && code_bytes == 1;
+        if (cb->variant == 2 && !kind0_fits) return PQHIP_EUNSUPPORTED;
         const int kind = (cb->variant == 2 || tiny) ? 0 : 2;
         dim3 grid;
         if (kind == 2) {
@@ -237,7 +240,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         static const char* const names[3][3] = {{"k_encode_mfma<odd>", "k_encode_mfma<vec2>", "k_encode_mfma<vec4>"},
                                                 {"", "", ""},
                                                 {"k_encode_mfma_lds3<odd>", "k_encode_mfma_lds3<vec2>", "k_encode_mfma_lds3<vec4>"}};
-        cb->last_kernel = names[kind][vec ? grp / 2 : 0];
+        cb->last_kernel = (!vec && cb->DP > 32) ? "k_encode_mfma_lds3<padded>" : names[kind][vec ? grp / 2 : 0];
     } else {
         const int64_t total = n * cb->M;
         const int block = 256;
@@ -371,16 +374,17 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
     // MFMA geometry: K <= 256 padded to {1,2,4,8} tiles of 32; dsub <= 32 padded to an even
     // number of k (one MFMA consumes two); A fragments must fit (T * DP/2 <= 128).
     int T = 0, DP = 0, groups = 1;
-    if (K <= 256 && dsub <= 32) {
-        const int tiles = (int)((K + 31) / 32);
-        T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
-        DP = (int)round_up(dsub, 2);
-        if (T * (DP / 2) > 128) { T = 0; DP = 0; }
-    } else if (K <= 65536 && dsub <= 32) {
-        // grouped: ceil(K / 256) virtual subquantizers of 8 tiles each per real one
-        T = 8;
-        DP = (int)round_up(dsub, 2);
-        groups = (int)((K + 255) / 256);
+    if (K <= 65536 && dsub <= 64) {
+        // sub-dimension: even padding up to 32, multiples of 8 for wide sub-vectors (33..64)
+        DP = dsub <= 32 ? (int)round_up(dsub, 2) : (int)round_up(dsub, 8);
+        if (K <= 256) {
+            const int tiles = (int)((K + 31) / 32);
+            T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;
+        } else {
+            // grouped: ceil(K / 256) virtual subquantizers of 8 tiles each per real one
+            T = 8;
+            groups = (int)((K + 255) / 256);
+        }
     }
     cb->T = T; cb->DP = DP; cb->groups = groups;
     cb->k_pad = T ? T * 32 * groups : (int)round_up(K, 32);

@@ -280,6 +280,30 @@ def test_more_than_256_centroids_on_the_matrix_path(ra, shape):
     assert gq.tobytes() == wq.tobytes() and gl.tobytes() == wl.tobytes()
 
 
+@pytest.mark.parametrize("dsub", [33, 36, 40, 41, 47, 48, 50, 56, 57, 60, 63, 64])
+def test_wide_subvectors_on_the_matrix_path(ra, dsub):
+    """32 < dsub <= 64: the default kernel with one wave per SIMD and 20..32-MFMA chains (DP = 40,
+    48, 56, 64 with zero k-padding) -- codes equal the oracle's, K <= 256 and grouped K > 256,
+    special values included; the k-means step on top of it."""
+    for (n, M, K) in [(777, 3, 256), (300, 2, 37), (500, 2, 300)]:
+        q = synth.normalish(1400 + dsub + K, (M, K, dsub))
+        x = synth.normalish(1401 + dsub + K, (n, M * dsub))
+        x[5, 3] = np.nan
+        x[6] *= np.float32(2e19)
+        x[7, :dsub] = q[0, K - 1]
+        dt = np.uint8 if K <= 256 else np.uint16
+        want = orc.quantize_batch(q, x, dtype=dt)
+        pq = _pq(ra, q)
+        assert pq.quantize_batch(x, dtype=dt).tobytes() == want.tobytes(), (n, M, K)
+        assert pq.last_encode_kernel().startswith("k_encode_mfma_lds3")
+        rec = pq.reconstruct_batch(want)
+        assert rec.tobytes() == orc.reconstruct_batch(q, want).tobytes()
+    q0, xs = _km_inputs(1200, 2, 16, dsub, 1500 + dsub)
+    wq, wl = orc.kmeans_iterations(q0, xs, n_iterations=2)
+    gq, gl = ra.kmeans_iterations(q0, xs, n_iterations=2)
+    assert gq.tobytes() == wq.tobytes() and gl.tobytes() == wl.tobytes()
+
+
 def test_strided_host_buffers(ra):
     M, K, dsub = 3, 32, 4
     q = synth.normalish(71, (M, K, dsub))
