@@ -21,6 +21,10 @@ done <<LIST
 768 48 256 4000000
 768 96 256 4000000
 768 24 256 4000000
+768 16 256 4000000
+768 12 256 4000000
+300 6 256 4000000
+300 15 1024 4000000
 128 16 256 10000000
 128 8 256 10000000
 128 64 16 10000000
