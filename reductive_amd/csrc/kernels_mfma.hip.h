@@ -52,59 +52,57 @@ __device__ __forceinline__ unsigned ord_key(float d)
     return (u >> 31) ? ~u : (u | 0x80000000u);
 }
 
-// Exact-by-construction tile evaluation used when a tile holds NaN/Inf/huge values or a negative
-// minimum: lanes of the lower half scan all K centroids with the literal three-operation distance
-// and the ordered-float comparison.  Rare; kept out of line so it costs the fast path no registers.
-// Everything is passed BY VALUE: taking the address of the kernel-argument struct would force a
-// copy of it into scratch memory in every wave (measured: 1.3 GB of spill writes per 10 M rows).
+// Exact-by-construction evaluation of single rows, used when a row holds NaN/Inf/huge values or its
+// fast minimum came out negative (a row that coincides with a centroid up to rounding -- every
+// instance that is its own cluster, every first k-means iteration started from instances).  For
+// each flagged row of the tile the WHOLE wave scans the K centroids (lane l takes l, l + 64, ..)
+// with the literal three-operation distance, then reduces under the ordered-float total order with
+// the lower index winning ties.  A flagged row costs a few microseconds, the other rows of the tile
+// keep their fast result.  (An earlier version re-did the whole tile with one lane per row: 0.4 ms
+// per affected tile, which made a 16 k-row k-means step ten times slower than it had to be.)
+// Out of line and with everything passed BY VALUE: taking the address of the kernel-argument struct
+// would force a copy of it into scratch memory in every wave (measured: 1.3 GB of spill writes per
+// 10 M rows).  groups > 0 selects the 64-bit key output of grouped codebooks (mv = virtual m).
+__device__ __forceinline__ bool of_equal(float a, float b) { return (a != a && b != b) || a == b; }
+
 template <typename IdxT>
-__device__ __noinline__ void encode_tile_slow_v(const float* x, int64_t x_rs, void* out, int64_t o_rs,
+__device__ __noinline__ void encode_rows_slow_v(const float* x, int64_t x_rs, void* out, int64_t o_rs,
                                                 const float* cb, const float* cc, int K, int dsub,
-                                                int k_pad, int m, int64_t row, bool valid)
+                                                int k_pad, int groups, int mv, int64_t row0, unsigned need)
 {
-    if (!valid || (threadIdx.x & 32)) return;
-    const float* xs = x + row * x_rs + (int64_t)m * dsub;
+    const int lane = threadIdx.x & 63;
+    const int m = groups > 0 ? mv / groups : mv;
     const float* cbm = cb + (int64_t)m * K * dsub;
     const float* ccm = cc + (int64_t)m * k_pad;
-    const float xx = norm_unrolled_global(xs, dsub);
-    int best = 0;
-    float bestd = 0.f;
-    for (int j = 0; j < K; ++j) {
-        const float dp = chain_dot_global(xs, 1, cbm + (int64_t)j * dsub, 1, dsub);
-        const float d = fsub(fadd(xx, ccm[j]), fadd(dp, dp));
-        if (j == 0 || of_less(d, bestd)) { bestd = d; best = j; }
+    while (need) {  // wave-uniform
+        const int jr = __builtin_ctz(need);
+        need &= need - 1;
+        const int64_t row = row0 + jr;
+        const float* xs = x + row * x_rs + (int64_t)m * dsub;
+        const float xx = norm_unrolled_global(xs, dsub);
+        float bd = 0.f;
+        int bj = 0x7fffffff;  // "no candidate yet"
+        for (int j = lane; j < K; j += 64) {
+            const float dp = chain_dot_global(xs, 1, cbm + (int64_t)j * dsub, 1, dsub);
+            const float d = fsub(fadd(xx, ccm[j]), fadd(dp, dp));
+            if (bj == 0x7fffffff || of_less(d, bd)) { bd = d; bj = j; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float od = __shfl_xor(bd, off);
+            const int oj = __shfl_xor(bj, off);
+            const bool take = oj != 0x7fffffff &&
+                              (bj == 0x7fffffff || of_less(od, bd) || (of_equal(od, bd) && oj < bj));
+            if (take) { bd = od; bj = oj; }
+        }
+        if (lane == 0) {
+            if (groups > 0)
+                reinterpret_cast<unsigned long long*>(out)[row * o_rs + mv] =
+                    ((unsigned long long)ord_key(bd) << 32) | (unsigned long long)(unsigned)bj;
+            else
+                reinterpret_cast<IdxT*>(out)[row * o_rs + mv] = (IdxT)bj;
+        }
     }
-    reinterpret_cast<IdxT*>(out)[row * o_rs + m] = (IdxT)best;
-}
-
-template <typename IdxT>
-__device__ __forceinline__ void encode_tile_slow(const EncodeArgs& a, int m, int64_t row, bool valid)
-{
-    encode_tile_slow_v<IdxT>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, m, row, valid);
-}
-
-// Grouped codebooks: the exact scan runs over ALL K centroids of the real subquantizer and leaves
-// its key in this virtual subquantizer's slot -- never worse than the group's own best, and on a
-// tie the full scan holds the lower index, so the merged minimum is the reference's answer.
-__device__ __noinline__ void encode_tile_slow_key_v(const float* x, int64_t x_rs, void* out, int64_t o_rs,
-                                                    const float* cb, const float* cc, int K, int dsub,
-                                                    int k_pad, int groups, int mv, int64_t row, bool valid)
-{
-    if (!valid || (threadIdx.x & 32)) return;
-    const int m = mv / groups;
-    const float* xs = x + row * x_rs + (int64_t)m * dsub;
-    const float* cbm = cb + (int64_t)m * K * dsub;
-    const float* ccm = cc + (int64_t)m * k_pad;
-    const float xx = norm_unrolled_global(xs, dsub);
-    int best = 0;
-    float bestd = 0.f;
-    for (int j = 0; j < K; ++j) {
-        const float dp = chain_dot_global(xs, 1, cbm + (int64_t)j * dsub, 1, dsub);
-        const float d = fsub(fadd(xx, ccm[j]), fadd(dp, dp));
-        if (j == 0 || of_less(d, bestd)) { bestd = d; best = j; }
-    }
-    reinterpret_cast<unsigned long long*>(out)[row * o_rs + mv] =
-        ((unsigned long long)ord_key(bestd) << 32) | (unsigned long long)(unsigned)best;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,11 +257,10 @@ __global__ __launch_bounds__(256, 2) void k_encode_mfma(EncodeArgs a)
         const int64_t row = row0 + j;
         const bool valid = row < a.n;
         // NaN / Inf / huge rows: the fast epilogue's fma shortcut is not valid -> exact slow path
-        if (__builtin_amdgcn_ballot_w64(!(xx < kBigNorm)) != 0ull) {
-            encode_tile_slow<IdxT>(a, m, row, valid);
-        } else if (h == 0 && valid) {
-            reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
-        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && !(xx < kBigNorm));
+        const unsigned need = (unsigned)(bal | (bal >> 32));  // rows of this tile that need the exact path
+        if (h == 0 && valid && !((need >> j) & 1u)) reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
+        if (need) encode_rows_slow_v<IdxT>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, 0, m, row0, need);
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = bop_n[s];
         xx = xx_n;

@@ -210,12 +210,9 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
 
         const int64_t row = row0 + j;
         const bool valid = row < a.n;
-        if (__builtin_amdgcn_ballot_w64(!(xx < kBigNorm) || neg) != 0ull) {
-            if (KEYS)
-                encode_tile_slow_key_v(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, a.groups, m, row, valid);
-            else
-                encode_tile_slow<IdxT>(a, m, row, valid);
-        } else if (h == 0 && valid) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && (!(xx < kBigNorm) || neg));
+        const unsigned need = (unsigned)(bal | (bal >> 32));  // rows of this tile that need the exact path
+        if (h == 0 && valid && !((need >> j) & 1u)) {
             if (KEYS) {
                 const float bd = (od < best) ? od : best;   // finite and >= 0 here
                 const unsigned gidx = (unsigned)bidx + 256u * (unsigned)(m - m_real * a.groups);
@@ -225,6 +222,9 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
                 reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
             }
         }
+        if (need)
+            encode_rows_slow_v<IdxT>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad,
+                                     KEYS ? a.groups : 0, m, row0, need);
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = bop_n[s];
         xx = xx_n;

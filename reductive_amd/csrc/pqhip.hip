@@ -215,8 +215,9 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         if (kind == 2) {
             // one workgroup = one subquantizer x 4 row streams (one per wave)
             static const int64_t rpi_max = [] { const char* e = getenv("PQHIP_DEBUG_RPI_MAX"); return e ? (int64_t)atoll(e) : (int64_t)1024; }();
+            static const int64_t rpi_min = [] { const char* e = getenv("PQHIP_DEBUG_RPI_MIN"); return e ? (int64_t)atoll(e) : (int64_t)32; }();
             int64_t rpi = round_up((n * cb->M + 4 * 4096 - 1) / (4 * 4096), 32);
-            rpi = std::max<int64_t>(32, std::min<int64_t>(rpi_max, rpi));
+            rpi = std::max<int64_t>(rpi_min, std::min<int64_t>(rpi_max, rpi));
             a.rows_per_item = (int)rpi;
             a.n_chunks = (n + 4 * rpi - 1) / (4 * rpi);       // row groups
             a.chunks_per_xcd = (a.n_chunks + 7) / 8;
