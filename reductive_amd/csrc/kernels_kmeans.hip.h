@@ -97,10 +97,13 @@ __global__ __launch_bounds__(64) void k_km_scatter(const IdxT* __restrict__ code
     const int64_t rend = (row0 + rows_per_block < n) ? row0 + rows_per_block : n;
     unsigned* pm = perm + (int64_t)m * n_pad;
     const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned c_next = (row0 + lane < rend) ? (unsigned)codes[(row0 + lane) * c_rs + m] : 0u;
     for (int64_t r0 = row0; r0 < rend; r0 += 64) {
         const int64_t r = r0 + lane;
         const bool valid = r < rend;
-        unsigned c = valid ? (unsigned)codes[r * c_rs + m] : 0u;
+        unsigned c = c_next;
+        // the next step's codes are requested before this step's ranks are worked out
+        c_next = (r + 64 < rend) ? (unsigned)codes[(r + 64) * c_rs + m] : 0u;
         if (c >= (unsigned)K) c = 0u;  // cannot happen for codes written by the encode kernels
         uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
         for (int bit = 0; bit < nbits; ++bit) {
