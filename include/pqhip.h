@@ -176,6 +176,33 @@ int32_t pqhip_kmeans_iterations_f32_dev(pqhip_ctx *ctx, int32_t device_slot, flo
                                         int64_t x_row_stride, int32_t n_iterations, float *loss,
                                         void *stream);
 
+/*
+ * The device part of `Opq::train_iteration` (src/pq/opq.rs:156-195), i.e. everything of an OPQ
+ * training iteration except its LAPACK call:
+ *   rx = instances.dot(&projection)                                   (opq.rs:167)
+ *   update_subquantizers(centroids, rx)   -- one kmeans_iteration per subquantizer  (:168, :227-245)
+ *   quantized = quantize_batch::<usize>(centroids, rx); reconstruct_batch_into(centroids, quantized, rx)
+ *                                                                     (:176-182, no projection)
+ *   cross = instances.t().dot(&reconstructed)                         (first half of :191)
+ * quantizers [M][K][dsub] (host, in/out), projection [d][d] (host, in), instances d_x [n][d] resident
+ * in HBM on `device_slot`; cross [d][d] (host, out).  The caller finishes the iteration with
+ * `(u, _, vt) = cross.svd(); projection = u.dot(vt)` (opq.rs:191-192).  Every step follows the
+ * arithmetic rules of DESIGN.md section 3 (the cross product is rule 2 with k over the rows: chains
+ * restart every 256 rows, block results added in row order), so quantizers and cross are
+ * bit-identical to the reference's default build for the same projection.  Returns synchronised.
+ */
+int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx *ctx, int32_t device_slot, float *quantizers,
+                                     int64_t n_subquantizers, int64_t n_centroids, int64_t sub_dim,
+                                     const float *projection, const float *d_x, int64_t n_rows,
+                                     int64_t x_row_stride, float *cross, void *stream);
+
+/* out [da][db] (host) = a^T . b for device-resident a [n][da], b [n][db] (unit column strides) with
+ * the same rule-2 arithmetic: `a.t().dot(&b)` of ndarray (opq.rs:191). */
+int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float *d_a,
+                               int64_t a_row_stride, int64_t da, const float *d_b,
+                               int64_t b_row_stride, int64_t db, int64_t n_rows, float *out,
+                               void *stream);
+
 /* ---- knobs used by the test-suite and the bench (not part of the reference surface) -------- */
 /* force a kernel variant for encode: 0 = auto, 1 = scalar VALU anchor kernel,
  * 2 = MFMA kernel with VALU argmin, 3 = MFMA + LDS-atomic argmin with register-resident codebook

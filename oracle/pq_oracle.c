@@ -17,6 +17,7 @@
  *   src/linalg.rs:150-180      SquaredEuclideanDistance Ix2 x Ix2
  *   src/linalg.rs:118-148      SquaredEuclideanDistance Ix1 x Ix2
  *   src/kmeans.rs:166-198, 308-360  update_centroids, kmeans_iteration, mean_squared_error
+ *   src/pq/opq.rs:156-195      Opq::train_iteration without its LAPACK calls
  *                              ("next" row: the k-means step of PQ/OPQ training)
  *
  * PARITY STATUS.  The reference is Rust and cannot be compiled in this image
@@ -430,4 +431,79 @@ int pqo_kmeans_iterations(float *cb, int64_t M, int64_t K, int64_t dsub, const f
     return 0;
 }
 
-int pqo_abi_version(void) { return 2; }
+/* ---- OPQ training iteration (opq.rs:156-195), everything except LAPACK ------------------------ */
+/* C = A^T . B for A [n][da], B [n][db] (`instances.t().dot(&reconstructed)`, opq.rs:191): an
+ * ndarray 2-D dot = matrixmultiply sgemm, rule (2) with k running over the n ROWS: every output
+ * element is a sequential fmaf chain over the rows of a 256-row block, and the block results are
+ * added to C in block order with one rounded add each (the first block initialises C). */
+typedef struct { const float *a, *b; float *c; int64_t n, da, db, a_rs, b_rs, i0, i1; } xtb_job;
+
+static void *xtb_range(void *arg)
+{
+    xtb_job *j = (xtb_job *)arg;
+    float *ab = (float *)malloc(sizeof(float) * (size_t)j->db);
+    for (int64_t i = j->i0; i < j->i1; ++i) {
+        float *ci = j->c + i * j->db;
+        for (int64_t rb = 0; rb < j->n; rb += PQO_KC) {
+            const int64_t re = rb + PQO_KC < j->n ? rb + PQO_KC : j->n;
+            for (int64_t c = 0; c < j->db; ++c) ab[c] = 0.0f;
+            for (int64_t r = rb; r < re; ++r) {
+                const float av = j->a[r * j->a_rs + i];
+                const float *br = j->b + r * j->b_rs;
+                for (int64_t c = 0; c < j->db; ++c) ab[c] = fmaf(av, br[c], ab[c]);
+            }
+            if (rb == 0) for (int64_t c = 0; c < j->db; ++c) ci[c] = ab[c];
+            else for (int64_t c = 0; c < j->db; ++c) ci[c] = ci[c] + ab[c];
+        }
+        if (j->n == 0) for (int64_t c = 0; c < j->db; ++c) ci[c] = 0.0f;
+    }
+    free(ab);
+    return NULL;
+}
+
+void pqo_at_dot_b(const float *a, int64_t n, int64_t da, int64_t a_rs, const float *b, int64_t db,
+                  int64_t b_rs, float *c, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > da) n_threads = (int)(da > 0 ? da : 1);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    xtb_job *jobs = (xtb_job *)malloc(sizeof(xtb_job) * (size_t)n_threads);
+    const int64_t per = (da + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        xtb_job jb = {a, b, c, n, da, db, a_rs, b_rs, t * per, (t + 1) * per < da ? (t + 1) * per : da};
+        if (jb.i0 > da) jb.i0 = da;
+        jobs[t] = jb;
+        pthread_create(&th[t], NULL, xtb_range, &jobs[t]);
+    }
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+}
+
+/* The device part of Opq::train_iteration (opq.rs:156-195): rx = instances.dot(projection) (:167),
+ * update_subquantizers (:168 -> :227-245, one kmeans_iteration per subquantizer), the
+ * quantize -> reconstruct round trip on rx with the NEW centroids (:176-182, primitives without
+ * projection), and cross = instances.t().dot(&reconstructed) (:191).  The SVD of `cross` and
+ * projection = u.dot(vt) (:191-192) are LAPACK's and stay with the caller.
+ * cb [M][K][dsub] is updated in place; cross [d][d] is written. */
+int pqo_opq_train_step(float *cb, int64_t M, int64_t K, int64_t dsub, const float *P, const float *x,
+                       int64_t n, int64_t x_rs, int64_t x_cs, float *cross, int n_threads)
+{
+    const int64_t d = M * dsub;
+    float *rx = (float *)malloc(sizeof(float) * (size_t)(n * d + 1));
+    float *xc = (float *)malloc(sizeof(float) * (size_t)(n * d + 1));
+    int64_t *codes = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n * M + 1));
+    pqo_rotate(x, n, d, x_rs, x_cs, P, rx);
+    int rc = pqo_kmeans_iterations(cb, M, K, dsub, rx, n, d, 1, 1, NULL, n_threads);
+    if (!rc) rc = pqo_quantize_batch(cb, M, K, dsub, NULL, rx, n, d, 1, codes, 8, M, 1, n_threads);
+    if (!rc) rc = pqo_reconstruct_batch(cb, M, K, dsub, NULL, codes, 8, n, M, 1, rx, d, 1);
+    if (!rc) {
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t k = 0; k < d; ++k) xc[i * d + k] = x[i * x_rs + k * x_cs];
+        pqo_at_dot_b(xc, n, d, d, rx, d, d, cross, n_threads);
+    }
+    free(rx); free(xc); free(codes);
+    return rc;
+}
+
+int pqo_abi_version(void) { return 3; }

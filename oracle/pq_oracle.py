@@ -57,6 +57,10 @@ def lib():
         L.pqo_kmeans_iterations.restype = ctypes.c_int
         L.pqo_kmeans_iterations.argtypes = [_fp, _i64, _i64, _i64, _fp, _i64, _i64, _i64,
                                             ctypes.c_int, _fp, ctypes.c_int]
+        L.pqo_at_dot_b.restype = None
+        L.pqo_at_dot_b.argtypes = [_fp, _i64, _i64, _i64, _fp, _i64, _i64, _fp, ctypes.c_int]
+        L.pqo_opq_train_step.restype = ctypes.c_int
+        L.pqo_opq_train_step.argtypes = [_fp, _i64, _i64, _i64, _fp, _fp, _i64, _i64, _i64, _fp, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -195,3 +199,26 @@ def kmeans_iterations(quantizers, x, n_iterations=1, n_threads=1):
                                      _p(loss), n_threads)
     assert rc == 0, rc
     return q, loss
+
+
+# ---- OPQ training iteration without LAPACK (opq.rs:156-195) --------------------------------------
+def at_dot_b(a, b, n_threads=1):
+    """`a.t().dot(&b)` for row-major a [n, da], b [n, db] (rule 2 with k over the rows)."""
+    a, b = _f32c(a), _f32c(b)
+    assert a.shape[0] == b.shape[0]
+    out = np.zeros((a.shape[1], b.shape[1]), np.float32)
+    lib().pqo_at_dot_b(_p(a), a.shape[0], a.shape[1], a.shape[1], _p(b), b.shape[1], b.shape[1], _p(out), n_threads)
+    return out
+
+
+def opq_train_step(quantizers, projection, x, n_threads=1):
+    """Device part of Opq::train_iteration: returns (updated quantizers, cross = x^T . reconstructed)."""
+    q = _f32c(quantizers).copy()
+    M, K, dsub = q.shape
+    P = _f32c(projection)
+    x = np.asarray(x, dtype=np.float32)
+    rs, cs = _estrides(x)
+    cross = np.zeros((M * dsub, M * dsub), np.float32)
+    rc = lib().pqo_opq_train_step(_p(q), M, K, dsub, _p(P), _p(x), x.shape[0], rs, cs, _p(cross), n_threads)
+    assert rc == 0, rc
+    return q, cross

@@ -94,6 +94,10 @@ def lib():
     L.pqhip_kmeans_iterations_f32.argtypes = [vp, fp, i64, i64, i64, vp, i64, i64, i64, i32, fp]
     L.pqhip_kmeans_iterations_f32_dev.restype = i32
     L.pqhip_kmeans_iterations_f32_dev.argtypes = [vp, i32, fp, i64, i64, i64, vp, i64, i64, i32, fp, vp]
+    L.pqhip_opq_train_step_f32_dev.restype = i32
+    L.pqhip_opq_train_step_f32_dev.argtypes = [vp, i32, fp, i64, i64, i64, fp, vp, i64, i64, fp, vp]
+    L.pqhip_at_dot_b_f32_dev.restype = i32
+    L.pqhip_at_dot_b_f32_dev.argtypes = [vp, i32, vp, i64, i64, vp, i64, i64, i64, fp, vp]
     L.pqhip_set_encode_variant.restype = i32
     L.pqhip_set_encode_variant.argtypes = [vp, i32]
     L.pqhip_last_encode_kernel.restype = ctypes.c_char_p
@@ -114,5 +118,6 @@ EXPORTS = [
     "pqhip_codebook_has_projection", "pqhip_quantize_batch_f32", "pqhip_reconstruct_batch_f32",
     "pqhip_quantize_batch_f32_dev", "pqhip_reconstruct_batch_f32_dev", "pqhip_reconstruct_rows_f32_dev", "pqhip_check_codes_dev",
     "pqhip_cluster_assignments_f32", "pqhip_kmeans_iterations_f32", "pqhip_kmeans_iterations_f32_dev",
+    "pqhip_opq_train_step_f32_dev", "pqhip_at_dot_b_f32_dev",
     "pqhip_set_encode_variant", "pqhip_last_encode_kernel", "pqhip_selftest_mfma_chain",
 ]

@@ -329,4 +329,76 @@ __global__ __launch_bounds__(256) void k_km_loss(const float* __restrict__ x, in
     if (threadIdx.x == 0) loss[m] = __fdiv_rn(s, inv_len_den);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// C = A^T . B over the rows (`instances.t().dot(&reconstructed)`, opq.rs:191) with rule-2
+// arithmetic: per output element one fmaf chain over the rows of each 256-row block, the block
+// results added to C in block order.  The chains of different blocks are independent, so phase 1
+// runs them all at once on the matrix cores (one wave = one 256-row block x one 64 x 64 macro tile
+// = 4 MFMA tiles, operands straight from HBM/L2: lane (i, h) of a k-step reads A[r0 + 2s + h][i],
+// 128 contiguous bytes per half-wave) and leaves one partial matrix per block; phase 2 folds the
+// partials in block order with one rounded add each (one lane per output element).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_atb_blocks(const float* __restrict__ A, int64_t a_rs, int da,
+                                                    const float* __restrict__ B, int64_t b_rs, int db,
+                                                    int64_t n, int64_t block0, int nblocks, int ti, int tj,
+                                                    int pa, int pb, float* __restrict__ part)
+{
+    // grid.x = ceil(nblocks / 4) * ti * tj; wave w of workgroup g: block 4 * (g / (ti*tj)) + w
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mt = blockIdx.x % (ti * tj);
+    const int bl = 4 * (blockIdx.x / (ti * tj)) + wave;  // block inside this group of blocks
+    if (bl >= nblocks) return;
+    const int I = mt / tj, J = mt - I * tj;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t r0 = (block0 + bl) * (int64_t)kKC;
+    const int ca0 = 64 * I + j, ca1 = ca0 + 32, cb0 = 64 * J + j, cb1 = cb0 + 32;
+    const bool va0 = ca0 < da, va1 = ca1 < da, vb0 = cb0 < db, vb1 = cb1 < db;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
+    constexpr int U = 4;  // k-steps whose operands are requested together
+    for (int s = 0; s < kKC / 2; s += U) {
+        float a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + 2 * (s + u) + h;
+            const bool vr = r < n;
+            const float* ar = A + r * a_rs;
+            const float* br = B + r * b_rs;
+            a0[u] = (vr && va0) ? ar[ca0] : 0.f;
+            a1[u] = (vr && va1) ? ar[ca1] : 0.f;
+            b0[u] = (vr && vb0) ? br[cb0] : 0.f;
+            b1[u] = (vr && vb1) ? br[cb1] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], c11, 0, 0, 0);
+        }
+    }
+    float* p = part + (int64_t)bl * pa * pb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        p[(int64_t)(64 * I + i) * pb + 64 * J + j] = c00[r];
+        p[(int64_t)(64 * I + i) * pb + 64 * J + 32 + j] = c01[r];
+        p[(int64_t)(64 * I + 32 + i) * pb + 64 * J + j] = c10[r];
+        p[(int64_t)(64 * I + 32 + i) * pb + 64 * J + 32 + j] = c11[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_atb_fold(const float* __restrict__ part, int nblocks, int pa, int pb,
+                                                  int first, float* __restrict__ C)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)pa * pb;
+    if (idx >= total) return;
+    float c = first ? part[idx] : C[idx];
+#pragma unroll 8
+    for (int b = first ? 1 : 0; b < nblocks; ++b) c = fadd(c, part[(int64_t)b * total + idx]);
+    C[idx] = c;
+}
+
 }  // namespace pqhip

@@ -578,6 +578,36 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
     return PQHIP_OK;
 }
 
+// C[da][db] (device, row stride pb floats, padded to multiples of 64) = A^T . B over n rows with
+// rule-2 arithmetic (k_atb_blocks / k_atb_fold).  Row blocks are processed in groups whose partial
+// matrices fit 256 MiB; the fold carries C from group to group, so the block order is the row order.
+int32_t atb_dev(const float* dA, int64_t a_rs, int da, const float* dB, int64_t b_rs, int db, int64_t n,
+                float* dC, int pa, int pb, hipStream_t st)
+{
+    if (n == 0) {
+        HIPCHK(hipMemsetAsync(dC, 0, (size_t)pa * pb * sizeof(float), st));
+        return PQHIP_OK;
+    }
+    const int ti = pa / 64, tj = pb / 64;
+    const int64_t total_blocks = (n + kKC - 1) / kKC;
+    const int64_t per = (int64_t)pa * pb * sizeof(float);
+    int64_t G = std::max<int64_t>(4, ((256ll << 20) / per) & ~3ll);
+    G = std::min<int64_t>(G, round_up(total_blocks, 4));
+    DevBuf part;
+    PQCHK(part.alloc((size_t)G * per));
+    for (int64_t g0 = 0; g0 < total_blocks; g0 += G) {
+        const int nb = (int)std::min<int64_t>(G, total_blocks - g0);
+        const unsigned grid = (unsigned)(((nb + 3) / 4) * ti * tj);
+        hipLaunchKernelGGL(k_atb_blocks, dim3(grid), dim3(256), 0, st, dA, a_rs, da, dB, b_rs, db, n, g0, nb, ti, tj,
+                           pa, pb, (float*)part.p);
+        hipLaunchKernelGGL(k_atb_fold, dim3((unsigned)(((int64_t)pa * pb + 255) / 256)), dim3(256), 0, st,
+                           (const float*)part.p, nb, pa, pb, g0 == 0 ? 1 : 0, dC);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));  // `part` is released on return
+    return PQHIP_OK;
+}
+
 int32_t ensure_scratch(pqhip_codebook* cb, int slot, int64_t rows)
 {
     CodebookDev& cd = cb->dev[slot];
@@ -755,7 +785,8 @@ void parallel_rows(int64_t rows, int max_threads, F fn)
 int pack_threads(const pqhip_ctx* ctx)
 {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return (int)std::max<unsigned>(1, std::min<unsigned>(8, hw / (unsigned)std::max<size_t>(1, ctx->devs.size())));
+    static const unsigned cap = [] { const char* e = getenv("PQHIP_PACK_THREADS"); return e ? (unsigned)std::max(1, atoi(e)) : 8u; }();
+    return (int)std::max<unsigned>(1, std::min<unsigned>(cap, hw / (unsigned)std::max<size_t>(1, ctx->devs.size())));
 }
 
 void store_code(void* base, int bytes, int64_t off, uint32_t v)
@@ -1165,6 +1196,62 @@ int32_t pqhip_kmeans_iterations_f32(pqhip_ctx* ctx, float* quantizers, int64_t M
     }
     return pqhip_kmeans_iterations_f32_dev(ctx, slot, quantizers, M, K, dsub, (const float*)dx.p, n, d,
                                            n_iterations, loss, (void*)ds.stream[0]);
+}
+
+// ---- "next" row: the device part of Opq::train_iteration (opq.rs:156-195) ------------------------
+int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx* ctx, int32_t slot, float* quantizers, int64_t M, int64_t K,
+                                     int64_t dsub, const float* projection, const float* d_x, int64_t n,
+                                     int64_t x_rs, float* cross, void* stream)
+{
+    if (!ctx || !quantizers || !projection || !cross || n < 0) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
+    if (M <= 0 || K <= 0 || dsub <= 0) return PQHIP_ESHAPE;
+    const int64_t d = M * dsub;
+    if (n > 0 && (!d_x || x_rs < d)) return PQHIP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->devs[slot]->ordinal));
+    pqhip_codebook* cb = nullptr;
+    PQCHK(codebook_create_impl(ctx, quantizers, M, K, dsub, projection, slot, &cb));
+    struct G { pqhip_codebook* p; ~G() { pqhip_codebook_destroy(p); } } g{cb};
+    CodebookDev& cd = cb->dev[slot];
+    hipStream_t st = (hipStream_t)stream;
+    const int code_bytes = K <= 256 ? 1 : 4;
+    const int pa = (int)round_up(d, 64);
+    DevBuf rx, codes, dcross;
+    PQCHK(rx.alloc((size_t)std::max<int64_t>(n, 1) * d * sizeof(float)));
+    PQCHK(codes.alloc((size_t)std::max<int64_t>(n, 1) * M * code_bytes));
+    PQCHK(dcross.alloc((size_t)pa * pa * sizeof(float)));
+    // opq.rs:167  rx = instances.dot(&projection)
+    PQCHK(rotate_dev(d_x, n, x_rs, cd.P, (int)d, (float*)rx.p, d, st));
+    // opq.rs:168  update_subquantizers: one kmeans_iteration per subquantizer on rx, loss discarded
+    PQCHK(kmeans_run_dev(cb, slot, (const float*)rx.p, n, d, 1, nullptr, st));
+    // opq.rs:176-182  quantize -> reconstruct round trip with the new centroids (rx is recycled)
+    PQCHK(encode_plain_dev(cb, slot, (const float*)rx.p, n, d, codes.p, code_bytes, M, st));
+    PQCHK(gather_dev(cb, slot, codes.p, code_bytes, n, M, (float*)rx.p, d, st));
+    // opq.rs:191  instances.t().dot(&reconstructed)
+    PQCHK(atb_dev(d_x, x_rs, (int)d, (const float*)rx.p, d, (int)d, n, (float*)dcross.p, pa, pa, st));
+    HIPCHK(hipMemcpy2DAsync(cross, (size_t)d * sizeof(float), dcross.p, (size_t)pa * sizeof(float),
+                            (size_t)d * sizeof(float), (size_t)d, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(quantizers, cd.cb, (size_t)(M * K * dsub) * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return PQHIP_OK;
+}
+
+int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx* ctx, int32_t slot, const float* d_a, int64_t a_rs, int64_t da,
+                               const float* d_b, int64_t b_rs, int64_t db, int64_t n, float* out, void* stream)
+{
+    if (!ctx || !out || n < 0 || da <= 0 || db <= 0 || da > 65536 || db > 65536) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
+    if (n > 0 && (!d_a || !d_b || a_rs < da || b_rs < db)) return PQHIP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->devs[slot]->ordinal));
+    hipStream_t st = (hipStream_t)stream;
+    const int pa = (int)round_up(da, 64), pb = (int)round_up(db, 64);
+    DevBuf dc;
+    PQCHK(dc.alloc((size_t)pa * pb * sizeof(float)));
+    PQCHK(atb_dev(d_a, a_rs, (int)da, d_b, b_rs, (int)db, n, (float*)dc.p, pa, pb, st));
+    HIPCHK(hipMemcpy2DAsync(out, (size_t)db * sizeof(float), dc.p, (size_t)pb * sizeof(float),
+                            (size_t)db * sizeof(float), (size_t)da, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return PQHIP_OK;
 }
 
 int32_t pqhip_selftest_mfma_chain(pqhip_ctx* ctx, int32_t slot, int32_t k, int32_t n_trials,

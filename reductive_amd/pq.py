@@ -205,6 +205,129 @@ def train_pq(n_subquantizers, n_subquantizer_bits, n_iterations, n_attempts, ins
     return Pq(None, best_q, ctx=ctx)
 
 
+def at_dot_b(a, b, ctx=None):
+    """`a.t().dot(&b)` (opq.rs:191) for CUDA float32 tensors a [n, da], b [n, db] on the GPU with the
+    reference's summation order over the rows; returns a numpy [da, db] array."""
+    import torch
+    assert a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.stride(1) == 1 and b.stride(1) == 1
+    ctx = ctx or default_ctx()
+    dev = a.device.index or 0
+    slot = dev if ctx.devices is None else ctx.devices.index(dev)
+    out = np.zeros((a.shape[1], b.shape[1]), np.float32)
+    rs = lambda t: t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+    rc = _lib.lib().pqhip_at_dot_b_f32_dev(ctx.handle, slot, a.data_ptr(), rs(a), a.shape[1], b.data_ptr(), rs(b),
+                                           b.shape[1], a.shape[0], out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                           ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+    if rc != _lib.OK:
+        raise _lib.PqHipError(rc, "pqhip_at_dot_b_f32_dev")
+    return out
+
+
+def opq_train_step(quantizers, projection, instances, ctx=None):
+    """The device part of `Opq::train_iteration` (opq.rs:156-195): rotation, one k-means iteration
+    per subquantizer, the quantize -> reconstruct round trip and `instances.t().dot(&reconstructed)`.
+    instances: CUDA float32 tensor [n, d].  Returns (updated quantizers, cross [d, d]); the caller
+    finishes with `u, _, vt = svd(cross); projection = u @ vt` (opq.rs:191-192)."""
+    import torch
+    q = np.array(quantizers, dtype=np.float32, order="C", copy=True)
+    if q.ndim != 3 or q.size == 0:
+        raise PanicError("Cannot cluster instances with zero centroids.")
+    M, K, dsub = q.shape
+    d = M * dsub
+    P = np.ascontiguousarray(projection, dtype=np.float32)
+    if list(P.shape) != [d, d]:
+        raise PanicError("Incorrect projection matrix shape, was: %s, should be [%d, %d]" % (list(P.shape), d, d))
+    x = instances
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    if x.shape[1] != d:
+        raise PanicError("Centroid and instance lengths differ.")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    ctx = ctx or default_ctx()
+    dev = x.device.index or 0
+    slot = dev if ctx.devices is None else ctx.devices.index(dev)
+    cross = np.zeros((d, d), np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = _lib.lib().pqhip_opq_train_step_f32_dev(
+        ctx.handle, slot, q.ctypes.data_as(fp), M, K, dsub, P.ctypes.data_as(fp), x.data_ptr(), x.shape[0],
+        x.stride(0) if x.shape[0] > 1 else max(x.stride(0), d), cross.ctypes.data_as(fp),
+        ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc != _lib.OK:
+        raise _lib.PqHipError(rc, "pqhip_opq_train_step_f32_dev")
+    return q, cross
+
+
+def bucket_eigenvalues(eigenvalues, n_buckets):
+    """`bucket_eigenvalues` (opq.rs:198-273): eigenvalue allocation of Ge et al. 2013 -- largest
+    first, each to the non-full bucket whose product (sum of shifted logs) is smallest."""
+    ev = np.asarray(eigenvalues, dtype=np.float32)
+    if n_buckets <= 0:
+        raise PanicError("Cannot distribute eigenvalues over zero buckets.")
+    if ev.shape[0] < n_buckets:
+        raise PanicError("At least one eigenvalue is required per bucket")
+    if ev.shape[0] % n_buckets != 0:
+        raise PanicError("The number of eigenvalues should be a multiple of the number of buckets.")
+    order = sorted(range(ev.shape[0]), key=lambda i: (np.isnan(ev[i]), ev[i]))     # ascending, NaN last
+    eps = np.finfo(np.float32).eps
+    if not ev[order[0]] >= -eps:
+        raise PanicError("Bucketing is only supported for positive eigenvalues.")
+    logs = np.log(ev + eps).astype(np.float32)
+    logs = (logs - logs.min()).astype(np.float32)
+    assignments = [[] for _ in range(n_buckets)]
+    products = [np.float32(0)] * n_buckets
+    cap = ev.shape[0] // n_buckets
+    while order:
+        i = order.pop()
+        open_buckets = [b for b in range(n_buckets) if len(assignments[b]) < cap]
+        b = min(open_buckets, key=lambda k: (products[k], k))                          # first minimum
+        assignments[b].append(i)
+        products[b] = np.float32(products[b] + logs[i])
+    return assignments
+
+
+def train_opq(n_subquantizers, n_subquantizer_bits, n_iterations, n_attempts, instances, rng=None, ctx=None):
+    """`Opq::train_pq_using` (opq.rs:44-99) with every data-sized step on the GPU: the iteration's
+    rotation, k-means update, quantize -> reconstruct round trip and cross product run in
+    `opq_train_step`; what stays on the host is LAPACK (covariance eigen-decomposition for the
+    initial projection, opq.rs:101-137; one d x d SVD per iteration, opq.rs:191-192) and the
+    random draw of the initial centroids (numpy's generator, not the reference's stream).
+    `n_attempts` has no effect, as in the reference (opq.rs:34-36)."""
+    import torch
+    x = np.asarray(instances, dtype=np.float32)
+    n, d = x.shape
+    M, K = n_subquantizers, 1 << n_subquantizer_bits
+    if M == 0 or M > d:
+        raise ReductiveError("The number of subquantizers must be between 1 and %d, was %d" % (d, M))
+    max_bits = int(np.trunc(np.log2(float(n)))) if n > 0 else 0
+    if n_subquantizer_bits == 0 or n_subquantizer_bits > max_bits:
+        raise ReductiveError("The number of subquantizers bits must be between 1 and %d" % max_bits)
+    if d % M != 0:
+        raise ReductiveError("The number of columns (%d) is not exactly dividable by the number of "
+                             "subquantizers (%d)" % (M, d))
+    if n_iterations == 0:
+        raise ReductiveError("The number of quantization iterations must be >= 1")
+    rng = rng or np.random.default_rng(0)
+    dsub = d // M
+    # create_projection_matrix (opq.rs:101-137): principal directions, allocated to the subquantizers
+    centered = x - x.mean(axis=0, dtype=np.float32)
+    cov = (centered.T @ (centered / np.float32(n - 1))).astype(np.float32)              # linalg.rs:23-44
+    evals, evecs = np.linalg.eigh(cov, UPLO="U")
+    P = np.zeros((d, d), np.float32)
+    for col, direction in enumerate(i for b in bucket_eigenvalues(evals, M) for i in b):
+        P[:, col] = evecs[:, direction]
+    # initial centroids: K distinct rows of rx per subquantizer (opq.rs:139-158)
+    q = np.stack([(x[rng.choice(n, K, replace=False)] @ P)[:, m * dsub:(m + 1) * dsub] for m in range(M)]).astype(np.float32)
+    ctx = ctx or default_ctx()
+    dev = torch.device("cuda", (ctx.devices[0] if ctx.devices else 0))
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    for _ in range(n_iterations):
+        q, cross = opq_train_step(q, P, xd, ctx=ctx)
+        u, _, vt = np.linalg.svd(cross)                                                   # opq.rs:191
+        P = (u @ vt).astype(np.float32)                                                   # opq.rs:192
+    return Pq(P, q, ctx=ctx)
+
+
 class Pq:
     """Product quantizer (Jegou et al., 2011) -- mirror of `reductive::pq::Pq<f32>`."""
 

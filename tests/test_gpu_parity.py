@@ -848,3 +848,56 @@ def test_lookup_rows_matches_select_reconstruct_scale(ra, shape):
     with pytest.raises(ra.PanicError):
         pq.reconstruct_rows_device(tc, bad, scales=ts, check=True)
     assert pq.reconstruct_rows_device(tc, tr[:0]).shape == (0, d)
+
+
+# ---- "next" row: the OPQ training iteration without its LAPACK calls (opq.rs:156-195) ------------
+@pytest.mark.parametrize("shape", [(700, 3, 8, 4), (5000, 15, 256, 20), (1030, 2, 37, 7), (300, 1, 300, 16), (513, 4, 16, 33)])
+def test_opq_train_step_matches_oracle(ra, shape):
+    import torch
+    n, M, K, dsub = shape
+    d = M * dsub
+    q0, x = _km_inputs(n, M, K, dsub, 1600 + n)
+    P = synth.orthonormal(1601 + n, d)
+    want_q, want_cross = orc.opq_train_step(q0, P, x, n_threads=8)
+    xd = torch.from_numpy(x).cuda()
+    got_q, got_cross = ra.opq_train_step(q0, P, xd)
+    assert got_q.tobytes() == want_q.tobytes()
+    assert got_cross.tobytes() == want_cross.tobytes()
+    # a padded, strided resident matrix gives the same bits
+    wide = torch.zeros((n, d + 5), device="cuda")
+    wide[:, :d] = xd
+    got_q2, got_cross2 = ra.opq_train_step(q0, P, wide[:, :d])
+    assert got_q2.tobytes() == want_q.tobytes() and got_cross2.tobytes() == want_cross.tobytes()
+
+
+def test_at_dot_b_row_blocks_and_groups(ra):
+    """`a.t().dot(&b)`: chains restart every 256 rows, block results are added in row order --
+    across the 256 MiB partial-matrix groups too (300 x 300 outputs: 640 blocks per group)."""
+    import torch
+    for (n, da, db) in [(1, 3, 5), (255, 7, 7), (256, 64, 65), (257, 20, 300), (3000, 130, 40)]:
+        a = synth.normalish(1700 + n, (n, da))
+        b = synth.normalish(1701 + n, (n, db))
+        got = ra.at_dot_b(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+        assert got.tobytes() == orc.at_dot_b(a, b, n_threads=8).tobytes(), (n, da, db)
+    n = 256 * 700 + 11                                     # two groups of row blocks at d = 300
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn((n, 300), device="cuda", generator=g)
+    b = torch.randn((n, 300), device="cuda", generator=g)
+    got = ra.at_dot_b(a, b)
+    want = orc.at_dot_b(a.cpu().numpy(), b.cpu().numpy(), n_threads=os.cpu_count() or 8)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_train_opq_statistical_loss(ra, kats):
+    """opq.rs:331-340 (quantize_with_opq): U[0,1) 256 x 20, M = 10, 7 bits, 10 iterations -> mean
+    Euclidean reconstruction loss < 0.1 for a GPU-trained OPQ; the projection stays orthonormal."""
+    k = kats["opq_statistical"]
+    x = synth.uniform01(1800, (k["n"], k["d"]))
+    pq = ra.train_opq(k["n_subquantizers"], k["n_bits"], k["n_iterations"], 1, x, rng=np.random.default_rng(7))
+    P = pq.projection()
+    assert np.abs(P @ P.T - np.eye(k["d"], dtype=np.float32)).max() < 1e-4
+    rec = pq.reconstruct_batch(pq.quantize_batch(x))
+    loss = np.sqrt(((x - rec) ** 2).sum(axis=1)).mean()
+    assert loss < k["loss_bound"], loss
+    with pytest.raises(ra.ReductiveError):
+        ra.train_opq(3, 4, 10, 1, x)

@@ -125,6 +125,19 @@ def test_training_and_lookup_entry_points_fail_loudly_without_a_gpu(ra):
         ra.train_pq(2, 2, 0, 1, x)
 
 
+def test_bucket_eigenvalues_kats(ra, kats):
+    """opq.rs:303-329: the eigenvalue allocation of the initial OPQ projection (host-side logic)."""
+    k = kats["bucket_eigenvalues"]
+    for c in k["cases"]:
+        assert ra.bucket_eigenvalues(c["eigenvalues"], c["n_buckets"]) == c["expected"]
+    with pytest.raises(ra.PanicError, match="multiple of the number of buckets"):
+        ra.bucket_eigenvalues(k["uneven"]["eigenvalues"], k["uneven"]["n_buckets"])
+    with pytest.raises(ra.PanicError, match="zero buckets"):
+        ra.bucket_eigenvalues([1.0, 2.0], 0)
+    with pytest.raises(ra.PanicError, match="positive eigenvalues"):
+        ra.bucket_eigenvalues([-1.0, 2.0], 2)
+
+
 def test_bench_sharding_two_ranks_gloo():
     """bench.py's N>1 path on CPU: world_size 2 over gloo, --dry-run (no GPU work):
     every rank takes its own shard, timing is max-reduced, rank 0 prints one JSON line."""

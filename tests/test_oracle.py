@@ -255,3 +255,28 @@ def test_kmeans_three_spheres(kats):
     got = sorted(np.rint(q[0]).astype(int).tolist())
     assert got == k["expected_rounded_sorted"]
     assert loss[0] < 1e-3
+
+
+# ---- OPQ training iteration without LAPACK (opq.rs:156-195) --------------------------------------
+def test_at_dot_b_matches_exact_model_across_row_blocks():
+    n, da, db = 530, 3, 4                       # three 256-row blocks: chain restarts + block adds
+    a = synth.normalish(601, (n, da))
+    b = synth.normalish(602, (n, db))
+    got = orc.at_dot_b(a, b)
+    want = np.array([[ex.gemm_dot(list(a[:, i]), list(b[:, j])) for j in range(db)] for i in range(da)], np.float32)
+    assert got.tobytes() == want.tobytes()
+    assert orc.at_dot_b(a, b, n_threads=3).tobytes() == want.tobytes()
+
+
+def test_opq_train_step_composes_its_parts():
+    M, K, dsub, n = 3, 8, 4, 700
+    d = M * dsub
+    q0 = synth.normalish(611, (M, K, dsub))
+    x = synth.normalish(612, (n, d))
+    P = synth.orthonormal(613, d)
+    rx = orc.rotate(x, P)
+    q1, _ = orc.kmeans_iterations(q0, rx, 1)
+    rec = orc.reconstruct_batch(q1, orc.quantize_batch(q1, rx, dtype=np.uint64))
+    cross = orc.at_dot_b(x, rec)
+    got_q, got_cross = orc.opq_train_step(q0, P, x, n_threads=2)
+    assert got_q.tobytes() == q1.tobytes() and got_cross.tobytes() == cross.tobytes()
