@@ -43,6 +43,7 @@ WORKLOADS = {
     "opq_encode": "Opq rotate+encode {rows} x d=300 per GPU, M=15, K=256 (BASELINE configs[2])",
     "reconstruct": "Pq::reconstruct_batch {rows} u8 codes -> d=300 fp32 per GPU (BASELINE configs[3])",
     "lookup": "embedding lookup: {rows} random rows of a resident 10M x 15 u8 code matrix -> select + reconstruct + per-row rescale, d=300 fp32 (SURVEY 8f rank 2)",
+    "opq_train": "device part of Opq::train_iteration (rotate, k-means update, quantize->reconstruct, X^T.R), {rows} x d=300 per GPU, M=15, K=256",
     "kmeans": "kmeans_iteration on all 15 subquantizers (training step; SURVEY 8f rank 1), {rows} x d=300 per GPU, K=256",
 }
 
@@ -153,6 +154,15 @@ def main():
 
             def step():
                 pq.quantize_batch_device(src, out=dst)
+        if args.workload == "opq_train":
+            from reductive_amd.pq import opq_train_step
+            P0 = synth.orthonormal(44, D)
+            pick = torch.arange(K, device=dev) * (rows // K)
+            q0 = np.stack([src[(pick + 7 * m) % rows, m * DSUB:(m + 1) * DSUB].cpu().numpy() for m in range(M)])
+            state = {"q": q0}
+
+            def step():
+                state["q"], state["cross"] = opq_train_step(state["q"], P0, src, ctx=ctx)
         if args.workload == "kmeans":
             # one step = one kmeans_iteration (assign + update) of all M subquantizers over the
             # resident instances; the K timed steps are ONE library call with n_iterations = K,
@@ -219,6 +229,7 @@ def main():
                  "opq_encode": "vectors/sec OPQ rotate+encode " + shape,
                  "reconstruct": "vectors/sec PQ reconstruct " + shape,
                  "lookup": "vectors/sec select+reconstruct+rescale lookup " + shape,
+                 "opq_train": "vectors/sec per OPQ training iteration (device part) " + shape,
                  "kmeans": "vectors/sec per k-means iteration, all subquantizers " + shape}
         rec = {
             "metric": names[args.workload], "value": value, "unit": "vectors/s",
@@ -245,11 +256,14 @@ def main():
                                    "algorithmic_bytes_per_vector": BYTES_PER_VEC}
             else:
                 flop = FLOP_PER_VEC + (2 * D * D if args.workload == "opq_encode" else 0)
+                if args.workload == "opq_train":   # rotation + 2 assignments + cross product
+                    flop = 2 * D * D + 2 * FLOP_PER_VEC + 2 * D * D
                 ach = flop * rows / sec / 1e12
                 rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                                    "kernel": {"encode": extra["encode_kernel"], "opq_encode": "k_rotate_pblock5 + " + extra["encode_kernel"],
-                                              "kmeans": extra["encode_kernel"] + " + k_km_{hist,scan,scatter,segsum} + codebook prep (whole iteration)"}[args.workload],
+                                              "kmeans": extra["encode_kernel"] + " + k_km_{hist,scan,scatter,segsum} + codebook prep (whole iteration)",
+                                              "opq_train": "k_rotate_pblock5 + 2 x " + extra["encode_kernel"] + " + k_km_* + k_reconstruct + k_atb_blocks/fold (whole step)"}[args.workload],
                                    "avg_launch_ms": kernel_ms, "algorithmic_flop_per_vector": flop,
                                    "algorithmic_bytes_per_vector": BYTES_PER_VEC,
                                    "hbm_gbs": BYTES_PER_VEC * rows / sec / 1e9,

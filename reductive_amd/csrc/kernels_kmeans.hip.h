@@ -357,25 +357,31 @@ __global__ __launch_bounds__(256) void k_atb_blocks(const float* __restrict__ A,
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
     constexpr int U = 4;  // k-steps whose operands are requested together
-    for (int s = 0; s < kKC / 2; s += U) {
-        float a0[U], a1[U], b0[U], b1[U];
+    float a0[2][U], a1[2][U], b0[2][U], b1[2][U];
+    auto fetch = [&](int s, int buf) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t r = r0 + 2 * (s + u) + h;
             const bool vr = r < n;
             const float* ar = A + r * a_rs;
             const float* br = B + r * b_rs;
-            a0[u] = (vr && va0) ? ar[ca0] : 0.f;
-            a1[u] = (vr && va1) ? ar[ca1] : 0.f;
-            b0[u] = (vr && vb0) ? br[cb0] : 0.f;
-            b1[u] = (vr && vb1) ? br[cb1] : 0.f;
+            a0[buf][u] = (vr && va0) ? ar[ca0] : 0.f;
+            a1[buf][u] = (vr && va1) ? ar[ca1] : 0.f;
+            b0[buf][u] = (vr && vb0) ? br[cb0] : 0.f;
+            b1[buf][u] = (vr && vb1) ? br[cb1] : 0.f;
         }
+    };
+    fetch(0, 0);
+#pragma unroll 2
+    for (int s = 0; s < kKC / 2; s += U) {
+        const int buf = (s / U) & 1;
+        if (s + U < kKC / 2) fetch(s + U, buf ^ 1);  // next batch in flight behind this batch's chain
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], c11, 0, 0, 0);
+            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[buf][u], b0[buf][u], c00, 0, 0, 0);
+            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[buf][u], b1[buf][u], c01, 0, 0, 0);
+            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[buf][u], b0[buf][u], c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[buf][u], b1[buf][u], c11, 0, 0, 0);
         }
     }
     float* p = part + (int64_t)bl * pa * pb;

@@ -64,6 +64,11 @@ struct DeviceSlot {
     std::mutex mu;  // serialises host-resident calls and scratch (re)allocation on this device
     hipStream_t stream[2] = {nullptr, nullptr};
     Staging st[2];
+    // grow-only device workspaces of the training entry points (a 12 GB hipMalloc + hipFree per
+    // call costs ~0.4 s); used under `train_mu`, released with the context
+    std::mutex train_mu;
+    void* ws[3] = {nullptr, nullptr, nullptr};
+    size_t ws_bytes[3] = {0, 0, 0};
 };
 
 struct CodebookDev {
@@ -578,10 +583,19 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
     return PQHIP_OK;
 }
 
+int32_t ensure_ws(DeviceSlot& ds, int i, size_t bytes)
+{
+    if (ds.ws_bytes[i] >= bytes) return PQHIP_OK;
+    if (ds.ws[i]) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(ds.ws[i]); ds.ws[i] = nullptr; ds.ws_bytes[i] = 0; }
+    HIPCHK(hipMalloc(&ds.ws[i], bytes));
+    ds.ws_bytes[i] = bytes;
+    return PQHIP_OK;
+}
+
 // C[da][db] (device, row stride pb floats, padded to multiples of 64) = A^T . B over n rows with
 // rule-2 arithmetic (k_atb_blocks / k_atb_fold).  Row blocks are processed in groups whose partial
 // matrices fit 256 MiB; the fold carries C from group to group, so the block order is the row order.
-int32_t atb_dev(const float* dA, int64_t a_rs, int da, const float* dB, int64_t b_rs, int db, int64_t n,
+int32_t atb_dev(DeviceSlot& ds, const float* dA, int64_t a_rs, int da, const float* dB, int64_t b_rs, int db, int64_t n,
                 float* dC, int pa, int pb, hipStream_t st)
 {
     if (n == 0) {
@@ -593,18 +607,17 @@ int32_t atb_dev(const float* dA, int64_t a_rs, int da, const float* dB, int64_t 
     const int64_t per = (int64_t)pa * pb * sizeof(float);
     int64_t G = std::max<int64_t>(4, ((256ll << 20) / per) & ~3ll);
     G = std::min<int64_t>(G, round_up(total_blocks, 4));
-    DevBuf part;
-    PQCHK(part.alloc((size_t)G * per));
+    PQCHK(ensure_ws(ds, 2, (size_t)G * per));
+    float* part = (float*)ds.ws[2];
     for (int64_t g0 = 0; g0 < total_blocks; g0 += G) {
         const int nb = (int)std::min<int64_t>(G, total_blocks - g0);
         const unsigned grid = (unsigned)(((nb + 3) / 4) * ti * tj);
         hipLaunchKernelGGL(k_atb_blocks, dim3(grid), dim3(256), 0, st, dA, a_rs, da, dB, b_rs, db, n, g0, nb, ti, tj,
-                           pa, pb, (float*)part.p);
+                           pa, pb, part);
         hipLaunchKernelGGL(k_atb_fold, dim3((unsigned)(((int64_t)pa * pb + 255) / 256)), dim3(256), 0, st,
-                           (const float*)part.p, nb, pa, pb, g0 == 0 ? 1 : 0, dC);
+                           (const float*)part, nb, pa, pb, g0 == 0 ? 1 : 0, dC);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(st));  // `part` is released on return
     return PQHIP_OK;
 }
 
@@ -893,6 +906,8 @@ void pqhip_ctx_destroy(pqhip_ctx* ctx)
             if (ds->stream[i]) { (void)hipStreamSynchronize(ds->stream[i]); (void)hipStreamDestroy(ds->stream[i]); }
             free_staging(ds->st[i]);
         }
+        for (int i = 0; i < 3; ++i)
+            if (ds->ws[i]) (void)hipFree(ds->ws[i]);
     }
     delete ctx;
 }
@@ -1216,9 +1231,12 @@ int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx* ctx, int32_t slot, float* quanti
     hipStream_t st = (hipStream_t)stream;
     const int code_bytes = K <= 256 ? 1 : 4;
     const int pa = (int)round_up(d, 64);
-    DevBuf rx, codes, dcross;
-    PQCHK(rx.alloc((size_t)std::max<int64_t>(n, 1) * d * sizeof(float)));
-    PQCHK(codes.alloc((size_t)std::max<int64_t>(n, 1) * M * code_bytes));
+    DeviceSlot& ds = *ctx->devs[slot];
+    std::lock_guard<std::mutex> tg(ds.train_mu);
+    PQCHK(ensure_ws(ds, 0, (size_t)std::max<int64_t>(n, 1) * d * sizeof(float)));
+    PQCHK(ensure_ws(ds, 1, (size_t)std::max<int64_t>(n, 1) * M * code_bytes));
+    struct { void* p; } rx{ds.ws[0]}, codes{ds.ws[1]};
+    DevBuf dcross;
     PQCHK(dcross.alloc((size_t)pa * pa * sizeof(float)));
     // opq.rs:167  rx = instances.dot(&projection)
     PQCHK(rotate_dev(d_x, n, x_rs, cd.P, (int)d, (float*)rx.p, d, st));
@@ -1228,7 +1246,7 @@ int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx* ctx, int32_t slot, float* quanti
     PQCHK(encode_plain_dev(cb, slot, (const float*)rx.p, n, d, codes.p, code_bytes, M, st));
     PQCHK(gather_dev(cb, slot, codes.p, code_bytes, n, M, (float*)rx.p, d, st));
     // opq.rs:191  instances.t().dot(&reconstructed)
-    PQCHK(atb_dev(d_x, x_rs, (int)d, (const float*)rx.p, d, (int)d, n, (float*)dcross.p, pa, pa, st));
+    PQCHK(atb_dev(ds, d_x, x_rs, (int)d, (const float*)rx.p, d, (int)d, n, (float*)dcross.p, pa, pa, st));
     HIPCHK(hipMemcpy2DAsync(cross, (size_t)d * sizeof(float), dcross.p, (size_t)pa * sizeof(float),
                             (size_t)d * sizeof(float), (size_t)d, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(quantizers, cd.cb, (size_t)(M * K * dsub) * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1245,9 +1263,11 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx* ctx, int32_t slot, const float* d_a, i
     HIPCHK(hipSetDevice(ctx->devs[slot]->ordinal));
     hipStream_t st = (hipStream_t)stream;
     const int pa = (int)round_up(da, 64), pb = (int)round_up(db, 64);
+    DeviceSlot& ds = *ctx->devs[slot];
+    std::lock_guard<std::mutex> tg(ds.train_mu);
     DevBuf dc;
     PQCHK(dc.alloc((size_t)pa * pb * sizeof(float)));
-    PQCHK(atb_dev(d_a, a_rs, (int)da, d_b, b_rs, (int)db, n, (float*)dc.p, pa, pb, st));
+    PQCHK(atb_dev(ds, d_a, a_rs, (int)da, d_b, b_rs, (int)db, n, (float*)dc.p, pa, pb, st));
     HIPCHK(hipMemcpy2DAsync(out, (size_t)db * sizeof(float), dc.p, (size_t)pb * sizeof(float),
                             (size_t)db * sizeof(float), (size_t)da, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
