@@ -177,6 +177,21 @@ int32_t pqhip_kmeans_iterations_f32_dev(pqhip_ctx *ctx, int32_t device_slot, flo
                                         void *stream);
 
 /*
+ * Resident instance matrices for the training entry points (which iterate over the same rows many
+ * times): a row-major copy [n_rows][n_cols] of a host matrix (any element strides) in the HBM of
+ * `device_slot`.  pqhip_matrix_device_ptr() is what the *_dev entry points take as d_x (row stride
+ * n_cols).  A caller that has no device-memory management of its own (the Rust binding) uploads
+ * once per training run.
+ */
+typedef struct pqhip_matrix pqhip_matrix;
+int32_t pqhip_matrix_upload_f32(pqhip_ctx *ctx, int32_t device_slot, const float *x, int64_t n_rows,
+                                int64_t n_cols, int64_t x_row_stride, int64_t x_col_stride,
+                                pqhip_matrix **out);
+const float *pqhip_matrix_device_ptr(const pqhip_matrix *m);
+int64_t pqhip_matrix_rows(const pqhip_matrix *m);
+void pqhip_matrix_destroy(pqhip_matrix *m);
+
+/*
  * The device part of `Opq::train_iteration` (src/pq/opq.rs:156-195), i.e. everything of an OPQ
  * training iteration except its LAPACK call:
  *   rx = instances.dot(&projection)                                   (opq.rs:167)

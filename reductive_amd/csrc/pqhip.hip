@@ -91,6 +91,13 @@ struct pqhip_ctx {
     std::vector<std::unique_ptr<DeviceSlot>> devs;
 };
 
+struct pqhip_matrix {
+    pqhip_ctx* ctx = nullptr;
+    int slot = 0;
+    float* d = nullptr;
+    int64_t rows = 0, cols = 0;
+};
+
 struct pqhip_codebook {
     pqhip_ctx* ctx = nullptr;
     int64_t M = 0, K = 0, dsub = 0, d = 0;
@@ -1179,38 +1186,66 @@ int32_t pqhip_kmeans_iterations_f32(pqhip_ctx* ctx, float* quantizers, int64_t M
     if (n > 0 && (!x || x_rs < 0 || x_cs < 0)) return PQHIP_EINVAL;
     // the instances stay resident on the first device of the context for all iterations
     const int slot = 0;
-    DeviceSlot& ds = *ctx->devs[slot];
     const int64_t d = M * dsub;
-    DevBuf dx;
-    {
-        std::lock_guard<std::mutex> g(ds.mu);
-        HIPCHK(hipSetDevice(ds.ordinal));
-        PQCHK(dx.alloc((size_t)n * d * sizeof(float)));
-        const int64_t cap = std::min<int64_t>(kStageRows, std::max<int64_t>(n, 1));
-        for (int b = 0; b < 2; ++b) PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), 16));
-        const int nthreads = pack_threads(ctx);
-        int b = 0;
-        for (int64_t r0 = 0; r0 < n; r0 += cap, b ^= 1) {
-            const int64_t rows = std::min<int64_t>(cap, n - r0);
-            HIPCHK(hipStreamSynchronize(ds.stream[b]));
-            float* hin = (float*)ds.st[b].h_in;
-            parallel_rows(rows, nthreads, [&, r0, hin](int64_t ib, int64_t ie) {
-                if (x_cs == 1) {
-                    for (int64_t i = ib; i < ie; ++i)
-                        std::memcpy(hin + i * d, x + (r0 + i) * x_rs, (size_t)d * sizeof(float));
-                } else {
-                    for (int64_t i = ib; i < ie; ++i)
-                        for (int64_t k = 0; k < d; ++k) hin[i * d + k] = x[(r0 + i) * x_rs + k * x_cs];
-                }
-            });
-            HIPCHK(hipMemcpyAsync((float*)dx.p + r0 * d, hin, (size_t)rows * d * sizeof(float),
-                                  hipMemcpyHostToDevice, ds.stream[b]));
-        }
-        HIPCHK(hipStreamSynchronize(ds.stream[0]));
-        HIPCHK(hipStreamSynchronize(ds.stream[1]));
-    }
+    pqhip_matrix* mx = nullptr;
+    PQCHK(pqhip_matrix_upload_f32(ctx, slot, x, n, d, x_rs, x_cs, &mx));
+    struct MG { pqhip_matrix* p; ~MG() { pqhip_matrix_destroy(p); } } mg{mx};
+    struct { const float* p; } dx{mx->d};
+    DeviceSlot& ds = *ctx->devs[slot];
     return pqhip_kmeans_iterations_f32_dev(ctx, slot, quantizers, M, K, dsub, (const float*)dx.p, n, d,
                                            n_iterations, loss, (void*)ds.stream[0]);
+}
+
+// ---- resident instance matrices (training entry points iterate over the same rows many times) ----
+int32_t pqhip_matrix_upload_f32(pqhip_ctx* ctx, int32_t slot, const float* x, int64_t n, int64_t d, int64_t x_rs,
+                                int64_t x_cs, pqhip_matrix** out)
+{
+    if (!ctx || !out || n < 0 || d <= 0) return PQHIP_EINVAL;
+    *out = nullptr;
+    if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
+    if (n > 0 && (!x || x_rs < 0 || x_cs < 0)) return PQHIP_EINVAL;
+    DeviceSlot& ds = *ctx->devs[slot];
+    std::unique_ptr<pqhip_matrix> m(new pqhip_matrix());
+    m->ctx = ctx; m->slot = slot; m->rows = n; m->cols = d;
+    std::lock_guard<std::mutex> g(ds.mu);
+    HIPCHK(hipSetDevice(ds.ordinal));
+    HIPCHK(hipMalloc((void**)&m->d, (size_t)std::max<int64_t>(n, 1) * d * sizeof(float)));
+    struct Free { float* p; ~Free() { if (p) (void)hipFree(p); } } guard{m->d};
+    const int64_t cap = std::min<int64_t>(kStageRows, std::max<int64_t>(n, 1));
+    for (int b = 0; b < 2; ++b) PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), 16));
+    const int nthreads = pack_threads(ctx);
+    int b = 0;
+    for (int64_t r0 = 0; r0 < n; r0 += cap, b ^= 1) {
+        const int64_t rows = std::min<int64_t>(cap, n - r0);
+        HIPCHK(hipStreamSynchronize(ds.stream[b]));
+        float* hin = (float*)ds.st[b].h_in;
+        parallel_rows(rows, nthreads, [&, r0, hin](int64_t ib, int64_t ie) {
+            if (x_cs == 1) {
+                for (int64_t i = ib; i < ie; ++i)
+                    std::memcpy(hin + i * d, x + (r0 + i) * x_rs, (size_t)d * sizeof(float));
+            } else {
+                for (int64_t i = ib; i < ie; ++i)
+                    for (int64_t k = 0; k < d; ++k) hin[i * d + k] = x[(r0 + i) * x_rs + k * x_cs];
+            }
+        });
+        HIPCHK(hipMemcpyAsync(m->d + r0 * d, hin, (size_t)rows * d * sizeof(float), hipMemcpyHostToDevice, ds.stream[b]));
+    }
+    HIPCHK(hipStreamSynchronize(ds.stream[0]));
+    HIPCHK(hipStreamSynchronize(ds.stream[1]));
+    guard.p = nullptr;
+    *out = m.release();
+    return PQHIP_OK;
+}
+
+const float* pqhip_matrix_device_ptr(const pqhip_matrix* m) { return m ? m->d : nullptr; }
+int64_t pqhip_matrix_rows(const pqhip_matrix* m) { return m ? m->rows : 0; }
+
+void pqhip_matrix_destroy(pqhip_matrix* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->ctx->devs[m->slot]->ordinal);
+    if (m->d) (void)hipFree(m->d);
+    delete m;
 }
 
 // ---- "next" row: the device part of Opq::train_iteration (opq.rs:156-195) ------------------------

@@ -22,6 +22,8 @@ use ndarray::{ArrayViewMut3, ArrayBase, ArrayView2, ArrayView3, ArrayViewMut2, D
 pub struct pqhip_ctx { _p: [u8; 0] }
 #[repr(C)]
 pub struct pqhip_codebook { _p: [u8; 0] }
+#[repr(C)]
+pub struct pqhip_matrix { _p: [u8; 0] }
 
 pub const PQHIP_OK: i32 = 0;
 pub const PQHIP_ECODE_RANGE: i32 = 3;
@@ -49,6 +51,13 @@ extern "C" {
     pub fn pqhip_kmeans_iterations_f32(ctx: *mut pqhip_ctx, quantizers: *mut f32, n_subquantizers: i64,
         n_centroids: i64, sub_dim: i64, x: *const f32, n_rows: i64, x_row_stride: i64,
         x_col_stride: i64, n_iterations: i32, loss: *mut f32) -> i32;
+    pub fn pqhip_matrix_upload_f32(ctx: *mut pqhip_ctx, device_slot: i32, x: *const f32, n_rows: i64,
+        n_cols: i64, x_row_stride: i64, x_col_stride: i64, out: *mut *mut pqhip_matrix) -> i32;
+    pub fn pqhip_matrix_device_ptr(m: *const pqhip_matrix) -> *const f32;
+    pub fn pqhip_matrix_destroy(m: *mut pqhip_matrix);
+    pub fn pqhip_opq_train_step_f32_dev(ctx: *mut pqhip_ctx, device_slot: i32, quantizers: *mut f32,
+        n_subquantizers: i64, n_centroids: i64, sub_dim: i64, projection: *const f32, d_x: *const f32,
+        n_rows: i64, x_row_stride: i64, cross: *mut f32, stream: *mut c_void) -> i32;
 }
 
 /// Batches smaller than this stay on the CPU path (a launch + PCIe round trip is pointless).
@@ -159,3 +168,32 @@ where A: 'static + Copy, S: Data<Elem = A>,
         n_iterations as i32, loss_ptr) };
     rc == PQHIP_OK
 }
+
+
+/// Instances kept in HBM for the length of an OPQ training run (`Opq::train_pq_using`, opq.rs:44-99):
+/// upload once, then one `train_step` per iteration replaces opq.rs:167-182 and the GEMM of :191.
+pub struct ResidentInstances { m: *mut pqhip_matrix, rows: usize, cols: usize }
+impl ResidentInstances {
+    pub fn upload<S: Data<Elem = f32>>(x: &ArrayBase<S, Ix2>) -> Option<Self> {
+        let h = handles()?.lock().unwrap();
+        let (xs, mut m) = (x.strides(), std::ptr::null_mut());
+        if xs.iter().any(|&s| s < 0) { return None; }
+        let rc = unsafe { pqhip_matrix_upload_f32(h.ctx, 0, x.as_ptr(), x.nrows() as i64, x.ncols() as i64,
+            xs[0] as i64, xs[1] as i64, &mut m) };
+        if rc == PQHIP_OK { Some(Self { m, rows: x.nrows(), cols: x.ncols() }) } else { None }
+    }
+    /// In `Opq::train_iteration`: `if let Some(cross) = resident.train_step(projection.view(), centroids.view_mut())
+    /// { let (u, _, vt) = cross.svd(true, true).unwrap(); projection.assign(&u.unwrap().dot(&vt.unwrap())); return; }`
+    pub fn train_step(&self, projection: ArrayView2<f32>, mut quantizers: ArrayViewMut3<f32>) -> Option<ndarray::Array2<f32>> {
+        let h = handles()?.lock().unwrap();
+        let (m, k, dsub) = quantizers.dim();
+        if m * dsub != self.cols || !quantizers.is_standard_layout() { return None; }
+        let p = projection.as_standard_layout();
+        let mut cross = ndarray::Array2::<f32>::zeros((self.cols, self.cols));
+        let rc = unsafe { pqhip_opq_train_step_f32_dev(h.ctx, 0, quantizers.as_mut_ptr(), m as i64, k as i64, dsub as i64,
+            p.as_ptr(), pqhip_matrix_device_ptr(self.m), self.rows as i64, self.cols as i64, cross.as_mut_ptr(),
+            std::ptr::null_mut()) };
+        if rc == PQHIP_OK { Some(cross) } else { None }
+    }
+}
+impl Drop for ResidentInstances { fn drop(&mut self) { unsafe { pqhip_matrix_destroy(self.m) } } }

@@ -901,3 +901,38 @@ def test_train_opq_statistical_loss(ra, kats):
     assert loss < k["loss_bound"], loss
     with pytest.raises(ra.ReductiveError):
         ra.train_opq(3, 4, 10, 1, x)
+
+
+def test_resident_matrix_handle_feeds_the_training_entry_points(ra):
+    """pqhip_matrix_upload_f32: what a host-only binding (Rust) uses to keep the instances in HBM
+    across the k-means / OPQ iterations -- strided host matrix in, *_dev entry points on its pointer."""
+    from reductive_amd.pq import default_ctx
+    L = ra.lib()
+    n, M, K, dsub = 3000, 3, 16, 8
+    d = M * dsub
+    q0, x = _km_inputs(n, M, K, dsub, 1900)
+    big = np.zeros((n, 2 * d + 3), np.float32)
+    big[:, 1:1 + 2 * d:2] = x                              # column stride 2, row stride 2d + 3
+    view = big[:, 1:1 + 2 * d:2]
+    h = ctypes.c_void_p()
+    rc = L.pqhip_matrix_upload_f32(default_ctx().handle, 0, view.ctypes.data, n, d, view.strides[0] // 4,
+                                   view.strides[1] // 4, ctypes.byref(h))
+    assert rc == 0 and L.pqhip_matrix_rows(h) == n
+    ptr = L.pqhip_matrix_device_ptr(h)
+    fp = ctypes.POINTER(ctypes.c_float)
+    q = q0.copy()
+    loss = np.zeros(M, np.float32)
+    rc = L.pqhip_kmeans_iterations_f32_dev(default_ctx().handle, 0, q.ctypes.data_as(fp), M, K, dsub, ptr, n, d, 3,
+                                           loss.ctypes.data_as(fp), None)
+    assert rc == 0
+    wq, wl = orc.kmeans_iterations(q0, x, 3)
+    assert q.tobytes() == wq.tobytes() and loss.tobytes() == wl.tobytes()
+    P = synth.orthonormal(1901, d)
+    q = q0.copy()
+    cross = np.zeros((d, d), np.float32)
+    rc = L.pqhip_opq_train_step_f32_dev(default_ctx().handle, 0, q.ctypes.data_as(fp), M, K, dsub,
+                                        P.ctypes.data_as(fp), ptr, n, d, cross.ctypes.data_as(fp), None)
+    assert rc == 0
+    wq, wc = orc.opq_train_step(q0, P, x)
+    assert q.tobytes() == wq.tobytes() and cross.tobytes() == wc.tobytes()
+    L.pqhip_matrix_destroy(h)
