@@ -211,6 +211,12 @@ int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx *ctx, int32_t device_slot, float 
                                      const float *projection, const float *d_x, int64_t n_rows,
                                      int64_t x_row_stride, float *cross, void *stream);
 
+/* d_out [n][d] = d_x [n][d] . projection [d][d] (host) on the device with rule-2 arithmetic:
+ * `instances.dot(&projection)` of the training paths (opq.rs:62, gaussian_opq.rs:55).  Returns synchronised. */
+int32_t pqhip_rotate_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float *d_x, int64_t n_rows,
+                             int64_t x_row_stride, int64_t d, const float *projection, float *d_out,
+                             int64_t out_row_stride, void *stream);
+
 /* out [da][db] (host) = a^T . b for device-resident a [n][da], b [n][db] (unit column strides) with
  * the same rule-2 arithmetic: `a.t().dot(&b)` of ndarray (opq.rs:191). */
 int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float *d_a,

@@ -98,6 +98,8 @@ def lib():
     L.pqhip_opq_train_step_f32_dev.argtypes = [vp, i32, fp, i64, i64, i64, fp, vp, i64, i64, fp, vp]
     L.pqhip_at_dot_b_f32_dev.restype = i32
     L.pqhip_at_dot_b_f32_dev.argtypes = [vp, i32, vp, i64, i64, vp, i64, i64, i64, fp, vp]
+    L.pqhip_rotate_f32_dev.restype = i32
+    L.pqhip_rotate_f32_dev.argtypes = [vp, i32, vp, i64, i64, i64, fp, vp, i64, vp]
     L.pqhip_matrix_upload_f32.restype = i32
     L.pqhip_matrix_upload_f32.argtypes = [vp, i32, vp, i64, i64, i64, i64, ctypes.POINTER(vp)]
     L.pqhip_matrix_device_ptr.restype = vp
@@ -126,7 +128,7 @@ EXPORTS = [
     "pqhip_codebook_has_projection", "pqhip_quantize_batch_f32", "pqhip_reconstruct_batch_f32",
     "pqhip_quantize_batch_f32_dev", "pqhip_reconstruct_batch_f32_dev", "pqhip_reconstruct_rows_f32_dev", "pqhip_check_codes_dev",
     "pqhip_cluster_assignments_f32", "pqhip_kmeans_iterations_f32", "pqhip_kmeans_iterations_f32_dev",
-    "pqhip_opq_train_step_f32_dev", "pqhip_at_dot_b_f32_dev",
+    "pqhip_opq_train_step_f32_dev", "pqhip_at_dot_b_f32_dev", "pqhip_rotate_f32_dev",
     "pqhip_matrix_upload_f32", "pqhip_matrix_device_ptr", "pqhip_matrix_rows", "pqhip_matrix_destroy",
     "pqhip_set_encode_variant", "pqhip_last_encode_kernel", "pqhip_selftest_mfma_chain",
 ]

@@ -1289,6 +1289,22 @@ int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx* ctx, int32_t slot, float* quanti
     return PQHIP_OK;
 }
 
+int32_t pqhip_rotate_f32_dev(pqhip_ctx* ctx, int32_t slot, const float* d_x, int64_t n, int64_t x_rs, int64_t d,
+                             const float* projection, float* d_out, int64_t o_rs, void* stream)
+{
+    if (!ctx || !projection || n < 0 || d <= 0 || d > (1 << 24)) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
+    if (n > 0 && (!d_x || !d_out || x_rs < d || o_rs < d)) return PQHIP_EINVAL;
+    HIPCHK(hipSetDevice(ctx->devs[slot]->ordinal));
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf dp;
+    PQCHK(dp.alloc((size_t)d * d * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(dp.p, projection, (size_t)d * d * sizeof(float), hipMemcpyHostToDevice, st));
+    PQCHK(rotate_dev(d_x, n, x_rs, (const float*)dp.p, (int)d, d_out, o_rs, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return PQHIP_OK;
+}
+
 int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx* ctx, int32_t slot, const float* d_a, int64_t a_rs, int64_t da,
                                const float* d_b, int64_t b_rs, int64_t db, int64_t n, float* out, void* stream)
 {

@@ -286,6 +286,67 @@ def bucket_eigenvalues(eigenvalues, n_buckets):
     return assignments
 
 
+def create_projection_matrix(instances, n_subquantizers):
+    """`Opq::create_projection_matrix` (opq.rs:101-137): eigenvectors of the covariance matrix
+    (linalg.rs:23-44, LAPACK `eigh`, upper triangle), columns ordered by `bucket_eigenvalues`."""
+    x = np.asarray(instances, dtype=np.float32)
+    n, d = x.shape
+    if n == 0:
+        raise PanicError("Cannot compute a covariance from zero observations")
+    centered = x - x.mean(axis=0, dtype=np.float32)
+    cov = (centered.T @ (centered / np.float32(n - 1))).astype(np.float32)
+    evals, evecs = np.linalg.eigh(cov, UPLO="U")
+    P = np.zeros((d, d), np.float32)
+    for col, direction in enumerate(i for b in bucket_eigenvalues(evals, n_subquantizers) for i in b):
+        P[:, col] = evecs[:, direction]
+    return P
+
+
+def rotate(instances, projection, ctx=None):
+    """`instances.dot(&projection)` (opq.rs:62, gaussian_opq.rs:55) on the GPU with the reference's
+    summation order; CUDA float32 tensor [n, d] in, CUDA tensor out."""
+    import torch
+    x = instances
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    d = x.shape[1]
+    P = np.ascontiguousarray(projection, dtype=np.float32)
+    if list(P.shape) != [d, d]:
+        raise PanicError("Incorrect projection matrix shape, was: %s, should be [%d, %d]" % (list(P.shape), d, d))
+    ctx = ctx or default_ctx()
+    dev = x.device.index or 0
+    slot = dev if ctx.devices is None else ctx.devices.index(dev)
+    out = torch.empty((x.shape[0], d), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().pqhip_rotate_f32_dev(ctx.handle, slot, x.data_ptr(), x.shape[0],
+                                         x.stride(0) if x.shape[0] > 1 else max(x.stride(0), d), d,
+                                         P.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), out.data_ptr(), d,
+                                         ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc != _lib.OK:
+        raise _lib.PqHipError(rc, "pqhip_rotate_f32_dev")
+    return out
+
+
+def train_gaussian_opq(n_subquantizers, n_subquantizer_bits, n_iterations, n_attempts, instances, rng=None, ctx=None):
+    """`GaussianOpq::train_pq_using` (gaussian_opq.rs:33-68): the PCA / eigenvalue-allocation
+    projection of `create_projection_matrix`, then a plain PQ trained on the rotated instances
+    (rotation and k-means on the GPU)."""
+    import torch
+    x = np.asarray(instances, dtype=np.float32)
+    if x.ndim != 2 or n_subquantizers == 0 or n_subquantizers > x.shape[1]:
+        raise ReductiveError("The number of subquantizers must be between 1 and %d, was %d"
+                             % (x.shape[1] if x.ndim == 2 else 0, n_subquantizers))
+    if x.shape[1] % n_subquantizers != 0:
+        raise ReductiveError("The number of columns (%d) is not exactly dividable by the number of "
+                             "subquantizers (%d)" % (n_subquantizers, x.shape[1]))
+    P = create_projection_matrix(x, n_subquantizers)
+    ctx = ctx or default_ctx()
+    dev = torch.device("cuda", (ctx.devices[0] if ctx.devices else 0))
+    rx = rotate(torch.from_numpy(np.ascontiguousarray(x)).to(dev), P, ctx=ctx).cpu().numpy()
+    pq = train_pq(n_subquantizers, n_subquantizer_bits, n_iterations, n_attempts, rx, rng=rng, ctx=ctx)
+    return Pq(P, pq.subquantizers(), ctx=ctx)
+
+
 def train_opq(n_subquantizers, n_subquantizer_bits, n_iterations, n_attempts, instances, rng=None, ctx=None):
     """`Opq::train_pq_using` (opq.rs:44-99) with every data-sized step on the GPU: the iteration's
     rotation, k-means update, quantize -> reconstruct round trip and cross product run in
@@ -309,13 +370,7 @@ def train_opq(n_subquantizers, n_subquantizer_bits, n_iterations, n_attempts, in
         raise ReductiveError("The number of quantization iterations must be >= 1")
     rng = rng or np.random.default_rng(0)
     dsub = d // M
-    # create_projection_matrix (opq.rs:101-137): principal directions, allocated to the subquantizers
-    centered = x - x.mean(axis=0, dtype=np.float32)
-    cov = (centered.T @ (centered / np.float32(n - 1))).astype(np.float32)              # linalg.rs:23-44
-    evals, evecs = np.linalg.eigh(cov, UPLO="U")
-    P = np.zeros((d, d), np.float32)
-    for col, direction in enumerate(i for b in bucket_eigenvalues(evals, M) for i in b):
-        P[:, col] = evecs[:, direction]
+    P = create_projection_matrix(x, M)
     # initial centroids: K distinct rows of rx per subquantizer (opq.rs:139-158)
     q = np.stack([(x[rng.choice(n, K, replace=False)] @ P)[:, m * dsub:(m + 1) * dsub] for m in range(M)]).astype(np.float32)
     ctx = ctx or default_ctx()

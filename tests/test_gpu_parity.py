@@ -936,3 +936,20 @@ def test_resident_matrix_handle_feeds_the_training_entry_points(ra):
     wq, wc = orc.opq_train_step(q0, P, x)
     assert q.tobytes() == wq.tobytes() and cross.tobytes() == wc.tobytes()
     L.pqhip_matrix_destroy(h)
+
+
+def test_rotate_entry_point_and_gaussian_opq(ra, kats):
+    """`instances.dot(&projection)` alone (rule 2, bit-exact) and `GaussianOpq::train_pq_using`
+    (gaussian_opq.rs:99-108: mean Euclidean loss < 0.12 on U[0,1) 256 x 20)."""
+    import torch
+    for (n, d) in [(333, 20), (1000, 300), (70, 515)]:
+        x = synth.normalish(2000 + d, (n, d))
+        P = synth.orthonormal(2001 + d, d)
+        got = ra.rotate(torch.from_numpy(x).cuda(), P).cpu().numpy()
+        assert got.tobytes() == orc.rotate(x, P).tobytes()
+    k = kats["gaussian_opq_statistical"]
+    x = synth.uniform01(2002, (k["n"], k["d"]))
+    pq = ra.train_gaussian_opq(k["n_subquantizers"], k["n_bits"], k["n_iterations"], 1, x, rng=np.random.default_rng(3))
+    rec = pq.reconstruct_batch(pq.quantize_batch(x))
+    loss = np.sqrt(((x - rec) ** 2).sum(axis=1)).mean()
+    assert loss < k["loss_bound"], loss

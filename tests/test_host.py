@@ -136,6 +136,13 @@ def test_bucket_eigenvalues_kats(ra, kats):
         ra.bucket_eigenvalues([1.0, 2.0], 0)
     with pytest.raises(ra.PanicError, match="positive eigenvalues"):
         ra.bucket_eigenvalues([-1.0, 2.0], 2)
+    # linalg.rs:252-260: the covariance the initial projection is built from (host side, numpy)
+    c = kats["covariance"]
+    x = np.array(c["x"], np.float32)
+    centered = x - x.mean(axis=0, dtype=np.float32)
+    assert ((centered.T @ (centered / np.float32(len(x) - 1))).tolist()) == c["expected"]
+    P = ra.create_projection_matrix(synth.normalish(77, (50, 6)), 3)
+    assert np.abs(P.T @ P - np.eye(6, dtype=np.float32)).max() < 1e-5
 
 
 def test_bench_sharding_two_ranks_gloo():
