@@ -254,4 +254,49 @@ inline std::vector<float> kmeans_iterations(Context& ctx, std::vector<float>& qu
     return loss;
 }
 
+// Instances kept in HBM for a training run (pqhip_matrix_*): upload once, iterate many times.
+class ResidentMatrix {
+public:
+    ResidentMatrix(Context& ctx, View2<const float> x, int32_t device_slot = 0) : ctx_(ctx), slot_(device_slot), cols_(x.cols)
+    {
+        const int32_t rc = pqhip_matrix_upload_f32(ctx.handle(), device_slot, x.ptr, x.rows, x.cols, x.row_stride,
+                                                   x.col_stride, &m_);
+        if (rc != PQHIP_OK) throw HipError(rc, "pqhip_matrix_upload_f32");
+    }
+    ~ResidentMatrix() { pqhip_matrix_destroy(m_); }
+    ResidentMatrix(const ResidentMatrix&) = delete;
+    ResidentMatrix& operator=(const ResidentMatrix&) = delete;
+    const float* device_ptr() const { return pqhip_matrix_device_ptr(m_); }
+    int64_t rows() const { return pqhip_matrix_rows(m_); }
+    int64_t cols() const { return cols_; }
+    Context& context() const { return ctx_; }
+    int32_t slot() const { return slot_; }
+
+private:
+    Context& ctx_;
+    int32_t slot_;
+    int64_t cols_;
+    pqhip_matrix* m_ = nullptr;
+};
+
+// The device part of `Opq::train_iteration` (src/pq/opq.rs:156-195): rotation, k-means update,
+// quantize -> reconstruct round trip, `instances.t().dot(&reconstructed)`.  `quantizers` is updated in
+// place; returns cross [d][d]; the caller finishes with `svd(cross)` and `projection = u.dot(vt)`.
+inline std::vector<float> opq_train_step(const ResidentMatrix& instances, std::vector<float>& quantizers, int64_t M,
+                                         int64_t K, int64_t dsub, const std::vector<float>& projection)
+{
+    const int64_t d = M * dsub;
+    if ((int64_t)projection.size() != d * d)
+        throw Panic("Incorrect projection matrix shape, was: [" + std::to_string(projection.size()) + " elements], should be [" +
+                    std::to_string(d) + ", " + std::to_string(d) + "]");
+    if ((int64_t)quantizers.size() != M * K * dsub || instances.cols() != d)
+        throw Panic("Centroid and instance lengths differ.");
+    std::vector<float> cross((size_t)(d * d));
+    const int32_t rc = pqhip_opq_train_step_f32_dev(instances.context().handle(), instances.slot(), quantizers.data(), M, K,
+                                                    dsub, projection.data(), instances.device_ptr(), instances.rows(), d,
+                                                    cross.data(), nullptr);
+    if (rc != PQHIP_OK) throw HipError(rc, "pqhip_opq_train_step_f32_dev");
+    return cross;
+}
+
 }  // namespace reductive_amd

@@ -68,6 +68,24 @@ int main()
         CHECK(loss.size() == 1 && loss[0] == 2.0f / 18.0f);   // squared errors .25 .5 .25 .5 .25 .25 (exact), 18 elements
         CHECK(panics([&] { std::vector<float> q(6); kmeans_iterations(ctx, q, 1, 2, 3, View2<const float>(inst.data(), 9, 2), 1); }));
     }
+    {   // OPQ training step on resident instances: identity projection, centroids at their fixed point
+        Context ctx;
+        const std::vector<float> inst = {-1, -1, 0, 1, 1, 0, -2, -1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 2};
+        ResidentMatrix rm(ctx, View2<const float>(inst.data(), 6, 3));
+        CHECK(rm.rows() == 6 && rm.device_ptr() != nullptr);
+        std::vector<float> c = {0.5f, 0.5f, 0, -1.5f, -1, 0, 0, 0, 1.5f};
+        const std::vector<float> want = c;
+        const std::vector<float> eye = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        auto cross = opq_train_step(rm, c, 1, 3, 3, eye);
+        for (int i = 0; i < 9; ++i) CHECK(c[i] == want[i]);
+        // cross = X^T . reconstructed with reconstructed = centroid of every row: exact small sums
+        // rows -> centroids: (-1.5,-1,0) (0.5,0.5,0) (-1.5,-1,0) (0.5,0.5,0) (0,0,1.5) (0,0,1.5)
+        const float expect[9] = {-1 * -1.5f + 1 * 0.5f + -2 * -1.5f, -1 * -1.0f + 1 * 0.5f + -2 * -1.0f, 0,
+                                 -1 * -1.5f + 1 * 0.5f + -1 * -1.5f, -1 * -1.0f + 1 * 0.5f + -1 * -1.0f, 0,
+                                 0, 0, 1 * 1.5f + 2 * 1.5f};
+        for (int i = 0; i < 9; ++i) CHECK(cross[i] == expect[i]);
+        CHECK(panics([&] { std::vector<float> bad(4); opq_train_step(rm, c, 1, 3, 3, bad); }));
+    }
     std::printf("all checks passed (GPU)\n");
     return 0;
 }
