@@ -953,3 +953,47 @@ def test_rotate_entry_point_and_gaussian_opq(ra, kats):
     rec = pq.reconstruct_batch(pq.quantize_batch(x))
     loss = np.sqrt(((x - rec) ** 2).sum(axis=1)).mean()
     assert loss < k["loss_bound"], loss
+
+
+def test_concurrent_training_encode_and_lookup_callers(ra):
+    """Training entry points next to serving calls from other host threads on one device: k-means
+    (own aux stream), the OPQ step (shared per-device workspaces), encode, lookup -- every result
+    still equals the oracle's."""
+    import threading
+    import torch
+    n, M, K, dsub = 6000, 4, 32, 8
+    d = M * dsub
+    q0, x = _km_inputs(n, M, K, dsub, 2100)
+    P = synth.orthonormal(2101, d)
+    xd = torch.from_numpy(x).cuda()
+    pq = _pq(ra, q0)
+    codes_ref = orc.quantize_batch(q0, x)
+    codes_d = torch.from_numpy(codes_ref).cuda()
+    rows = torch.arange(n - 1, -1, -1, device="cuda")
+    want_km = orc.kmeans_iterations(q0, x, 4)
+    want_opq = orc.opq_train_step(q0, P, x)
+    want_rec = orc.reconstruct_batch(q0, codes_ref[::-1])
+    out, errs = {}, []
+
+    def guard(name, fn):
+        def run():
+            try:
+                for _ in range(3):
+                    out[name] = fn()
+            except Exception as e:     # noqa: BLE001 - surfaced below
+                errs.append((name, e))
+        return run
+    jobs = [guard("km", lambda: ra.kmeans_iterations(q0, xd, 4)),
+            guard("opq", lambda: ra.opq_train_step(q0, P, xd)),
+            guard("opq2", lambda: ra.opq_train_step(q0, P, xd)),
+            guard("enc", lambda: pq.quantize_batch(x)),
+            guard("look", lambda: pq.reconstruct_rows_device(codes_d, rows, check=True).cpu().numpy())]
+    th = [threading.Thread(target=j) for j in jobs]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert out["km"][0].tobytes() == want_km[0].tobytes() and out["km"][1].tobytes() == want_km[1].tobytes()
+    for k in ("opq", "opq2"):
+        assert out[k][0].tobytes() == want_opq[0].tobytes() and out[k][1].tobytes() == want_opq[1].tobytes()
+    assert out["enc"].tobytes() == codes_ref.tobytes()
+    assert out["look"].tobytes() == want_rec.tobytes()
