@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libpq_oracle.so")
+# PQO_SANITIZED=1: load the ASan/UBSan build instead (the process must have libasan preloaded)
+_SAN = os.environ.get("PQO_SANITIZED") == "1"
+_SO = os.path.join(_HERE, "libpq_oracle_san.so" if _SAN else "libpq_oracle.so")
 _lib = None
 
 _i64 = ctypes.c_int64
@@ -21,7 +23,7 @@ _vp = ctypes.c_void_p
 def build(force=False):
     src = os.path.join(_HERE, "pq_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"] + (["libpq_oracle_san.so"] if _SAN else []))
     return _SO
 
 

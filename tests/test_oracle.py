@@ -280,3 +280,24 @@ def test_opq_train_step_composes_its_parts():
     cross = orc.at_dot_b(x, rec)
     got_q, got_cross = orc.opq_train_step(q0, P, x, n_threads=2)
     assert got_q.tobytes() == q1.tobytes() and got_cross.tobytes() == cross.tobytes()
+
+
+def test_oracle_under_sanitizers():
+    """the CPU code runs under AddressSanitizer + UBSan (GPU sanitizers are not
+    available on the pool): this file's tests once more, in a child process, against the
+    -fsanitize=address,undefined build of oracle/pq_oracle.c."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("PQO_SANITIZED") == "1":
+        pytest.skip("already inside the sanitized run")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan not available")
+    env = dict(os.environ, PQO_SANITIZED="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_oracle.py"), "-x", "-q",
+                          "-m", "not gpu", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "passed" in out.stdout
