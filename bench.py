@@ -270,6 +270,18 @@ def main():
                                    "hbm_frac": BYTES_PER_VEC * rows / sec / 1e9 / PEAK_HBM_GBS}
             if world == 1 and not args.no_cpu_baseline and args.workload in ("encode", "opq_encode"):
                 rec["cpu_baseline"] = cpu_baseline(args, q, P, src, dst, pq)
+            if world == 1 and not args.no_cpu_baseline and args.workload == "reconstruct":
+                # BASELINE.md B-rec: the oracle's gather (primitives.rs:110-173 semantics, single thread as in
+                # the reference) on the first 1 M codes, and the GPU rows checked against it byte for byte
+                from oracle import pq_oracle as orc
+                n_s = min(1_000_000, rows)
+                c_host = src[:n_s].cpu().numpy()
+                t = time.perf_counter()
+                want = orc.reconstruct_batch(q, c_host)
+                t_cpu = time.perf_counter() - t
+                rec["cpu_baseline"] = {"value": n_s / t_cpu, "unit": "vectors/s", "cores": 1, "kind": "port",
+                                       "sample": "first %d code rows of the bench batch, oracle gather on one thread (%.1f s)" % (n_s, t_cpu),
+                                       "gpu_rows_identical_on_sample": bool(dst[:n_s].cpu().numpy().tobytes() == want.tobytes())}
             if world == 1 and not args.no_cpu_baseline and args.workload == "kmeans":
                 rec["cpu_baseline"] = cpu_baseline_kmeans(args, q0, src, ctx)
         print(json.dumps(rec), flush=True)
