@@ -40,6 +40,10 @@ struct EncodeArgs {
     // 64-bit key {ordered distance, global centroid index} per (row, virtual m) and k_merge_keys
     // takes the minimum over the groups.  groups == 1: plain codes.
     int groups;
+    // optional device flag "some ||c||^2 is not finite or too large" (k_check_norms): when it is set
+    // every row takes the exact path.  Lets a captured k-means iteration (hipGraph) stay correct
+    // without the host looking at the flag between iterations.  nullptr: the host has checked.
+    const int* bad_flag;
 };
 
 // Order-preserving map of an f32 distance onto u32 under ordered-float's total order
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mfma(EncodeArgs a)
     int64_t row_end = row_begin + a.rows_per_item;
     if (row_end > a.n) row_end = a.n;
     const float* xcol = a.x + (int64_t)m * a.dsub;
+    const bool bad_codebook = a.bad_flag != nullptr && *a.bad_flag != 0;  // wave-uniform
 
     auto load_tile = [&](float (&v)[DP], int64_t tile_row0) {
         int64_t row = tile_row0 + j;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_mfma(EncodeArgs a)
         const int64_t row = row0 + j;
         const bool valid = row < a.n;
         // NaN / Inf / huge rows: the fast epilogue's fma shortcut is not valid -> exact slow path
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && !(xx < kBigNorm));
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && (bad_codebook || !(xx < kBigNorm)));
         const unsigned need = (unsigned)(bal | (bal >> 32));  // rows of this tile that need the exact path
         if (h == 0 && valid && !((need >> j) & 1u)) reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
         if (need) encode_rows_slow_v<IdxT>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, 0, m, row0, need);

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
     constexpr bool KEYS = sizeof(IdxT) == 8;
     const int m_real = KEYS ? m / a.groups : m;
     const float* xcol = a.x + (int64_t)m_real * a.dsub;
+    const bool bad_codebook = a.bad_flag != nullptr && *a.bad_flag != 0;  // wave-uniform
 
     // x tile: lane j reads the DP floats of its row's sub-vector.  Rows past the end are clamped
     // to the last row (their result is never stored).
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
 
         const int64_t row = row0 + j;
         const bool valid = row < a.n;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && (!(xx < kBigNorm) || neg));
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && (bad_codebook || !(xx < kBigNorm) || neg));
         const unsigned need = (unsigned)(bal | (bal >> 32));  // rows of this tile that need the exact path
         if (h == 0 && valid && !((need >> j) & 1u)) {
             if (KEYS) {

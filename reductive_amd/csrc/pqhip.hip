@@ -175,6 +175,7 @@ int32_t encode_grouped_dev(pqhip_codebook* cb, int slot, const float* d_x, int64
         a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
         a.M = (int)Mv; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
         a.groups = cb->groups;
+        a.bad_flag = nullptr;
         int64_t rpi = round_up((rows * Mv + 4 * 4096 - 1) / (4 * 4096), 32);
         rpi = std::max<int64_t>(32, std::min<int64_t>(1024, rpi));
         a.rows_per_item = (int)rpi;
@@ -193,8 +194,11 @@ int32_t encode_grouped_dev(pqhip_codebook* cb, int slot, const float* d_x, int64
 }
 
 // PQ encode of device-resident, already rotated rows.
+// bad_flag != nullptr: the matrix-core kernel is launched whatever the host last knew about the
+// centroid norms and consults the device flag itself (captured k-means iterations).
 int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
-                         void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st)
+                         void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st,
+                         const int* bad_flag = nullptr)
 {
     if (n == 0) return PQHIP_OK;
     CodebookDev& cd = cb->dev[slot];
@@ -202,7 +206,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         return encode_grouped_dev(cb, slot, d_x, n, x_rs, d_codes, o_rs, st);
     // MFMA kernels: u8 codes from every variant, u32 codes (k-means assignments, wide index types)
     // from the default variant; K <= 256 here (larger K: encode_grouped_dev above, or the anchor)
-    const bool mfma_possible = cb->groups == 1 && cb->T != 0 && cb->norms_ok &&
+    const bool mfma_possible = cb->groups == 1 && cb->T != 0 && (cb->norms_ok || bad_flag != nullptr) &&
                                (code_bytes == 1 || (code_bytes == 4 && (cb->variant == 0 || cb->variant == 4)));
     bool use_mfma = mfma_possible;
     if (cb->variant == 1) use_mfma = false;
@@ -214,6 +218,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
         a.M = (int)cb->M; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
         a.groups = 1;
+        a.bad_flag = bad_flag;
         // kernel kind: 0 VALU argmin, 2 LDS argmin + LDS A fragments (variant 3, the retired
         // register-resident LDS-argmin kernel, is an alias of the default)
         // auto: for sub-vectors of <= 4 floats the per-distance work outweighs the MFMA chain and the
@@ -362,6 +367,28 @@ int32_t prepare_codebook_dev(pqhip_codebook* cb, int slot, hipStream_t st, bool*
     HIPCHK(hipMemcpyAsync(&bad, cd.err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     *norms_ok = bad == 0;
+    return PQHIP_OK;
+}
+
+// the same launches without looking at the flag (it stays on the device for the kernels to read)
+int32_t prepare_codebook_async(pqhip_codebook* cb, int slot, hipStream_t st)
+{
+    CodebookDev& cd = cb->dev[slot];
+    const int64_t M = cb->M, K = cb->K, dsub = cb->dsub;
+    HIPCHK(hipMemsetAsync(cd.err + 1, 0, sizeof(int), st));
+    const int total = (int)(M * cb->k_pad);
+    hipLaunchKernelGGL(k_centroid_norms, dim3((total + 255) / 256), dim3(256), 0, st, cd.cb,
+                       (int)M, (int)K, (int)dsub, cb->k_pad, cd.cc);
+    hipLaunchKernelGGL(k_check_norms, dim3((total + 255) / 256), dim3(256), 0, st, cd.cc,
+                       (int)M, (int)K, cb->k_pad, kBigNorm, cd.err + 1);
+    if (cb->T) {
+        const int S = cb->DP / 2;
+        const int tiles = cb->T * cb->groups;
+        const int64_t tot = M * tiles * S * 64;
+        hipLaunchKernelGGL(k_build_frags, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
+                           cd.cb, (int)M, (int)K, (int)dsub, tiles, S, cd.frags);
+    }
+    HIPCHK(hipGetLastError());
     return PQHIP_OK;
 }
 
@@ -521,22 +548,28 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
     HIPCHK(hipEventCreateWithFlags(&aux.done, hipEventDisableTiming));
     hipStream_t su = aux.s;
 
-    for (int it = 0; it < n_iterations; ++it) {
+    // One kmeans_iteration.  s_enc / s_upd: streams of the assignment and of the update (equal inside a
+    // captured graph); bad_flag: device flag consulted by the encode kernel instead of the host;
+    // with_loss: launch the exact loss fold; host_prep: rebuild the encode tables with the host reading
+    // the finite-norm flag (the per-iteration sync) rather than leaving it on the device.
+    auto iteration = [&](hipStream_t s_enc, hipStream_t s_upd, const int* bad_flag, bool with_loss, bool host_prep) -> int32_t {
         for (int w = 0; w < nwin; ++w) {
             const int64_t r0 = (int64_t)w * wrows, rows = std::min<int64_t>(wrows, n - r0);
             const float* xw = d_x + r0 * x_rs;
             char* cw = (char*)codes.p + r0 * M * code_bytes;
-            PQCHK(encode_plain_dev(cb, slot, xw, rows, x_rs, cw, code_bytes, M, st));
-            HIPCHK(hipEventRecord(aux.ev[w], st));
-            HIPCHK(hipStreamWaitEvent(su, aux.ev[w], 0));
+            PQCHK(encode_plain_dev(cb, slot, xw, rows, x_rs, cw, code_bytes, M, s_enc, bad_flag));
+            if (s_enc != s_upd) {
+                HIPCHK(hipEventRecord(aux.ev[w], s_enc));
+                HIPCHK(hipStreamWaitEvent(s_upd, aux.ev[w], 0));
+            }
             const int nb = (int)((rows + rpb - 1) / rpb);
             const dim3 gbm((unsigned)nb, (unsigned)M);
 #define KM_LAUNCH(IDX)                                                                                   \
-            hipLaunchKernelGGL((k_km_hist<IDX>), gbm, dim3(256), lds_k, su, (const IDX*)cw, rows, M, (int)K, \
+            hipLaunchKernelGGL((k_km_hist<IDX>), gbm, dim3(256), lds_k, s_upd, (const IDX*)cw, rows, M, (int)K, \
                                (int)rpb, nb, (unsigned*)counts.p);                                       \
-            hipLaunchKernelGGL(k_km_scan, dim3((unsigned)M), dim3(256), lds_scan, su, (unsigned*)counts.p, \
+            hipLaunchKernelGGL(k_km_scan, dim3((unsigned)M), dim3(256), lds_scan, s_upd, (unsigned*)counts.p, \
                                (int)K, nb, (unsigned*)seg.p);                                            \
-            hipLaunchKernelGGL((k_km_scatter<IDX>), gbm, dim3(64), lds_k, su, (const IDX*)cw, rows, M,   \
+            hipLaunchKernelGGL((k_km_scatter<IDX>), gbm, dim3(64), lds_k, s_upd, (const IDX*)cw, rows, M, \
                                (int)K, (int)rpb, nb, (const unsigned*)counts.p, (const unsigned*)seg.p,  \
                                (unsigned*)perm.p, w_pad)
             if (code_bytes == 1) { KM_LAUNCH(uint8_t); } else { KM_LAUNCH(uint32_t); }
@@ -552,37 +585,85 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
                 const size_t slab = (size_t)4 * 8 * (64 / qq) * dsub * sizeof(float);
                 const dim3 g((unsigned)((M * K + 3) / 4));
                 if (vec4)
-                    hipLaunchKernelGGL((k_km_segsum_w<true>), g, dim3(256), slab, su, gw, g_rs, g_ms, w_pad,
+                    hipLaunchKernelGGL((k_km_segsum_w<true>), g, dim3(256), slab, s_upd, gw, g_rs, g_ms, w_pad,
                                        (const unsigned*)perm.p, (const unsigned*)seg.p, (int)M, (int)K, (int)dsub,
                                        (float*)acc.p, tin, tout, first, last);
                 else
-                    hipLaunchKernelGGL((k_km_segsum_w<false>), g, dim3(256), slab, su, gw, g_rs, g_ms, w_pad,
+                    hipLaunchKernelGGL((k_km_segsum_w<false>), g, dim3(256), slab, s_upd, gw, g_rs, g_ms, w_pad,
                                        (const unsigned*)perm.p, (const unsigned*)seg.p, (int)M, (int)K, (int)dsub,
                                        (float*)acc.p, tin, tout, first, last);
             } else {
-                hipLaunchKernelGGL(k_km_segsum, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, su, gw, g_rs, g_ms, w_pad,
+                hipLaunchKernelGGL(k_km_segsum, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s_upd, gw, g_rs, g_ms, w_pad,
                                    (const unsigned*)perm.p, (const unsigned*)seg.p, (int)M, (int)K, (int)dsub,
                                    (float*)acc.p, tin, tout, first, last);
             }
             HIPCHK(hipGetLastError());
         }
         // the new centroids replace the old ones only after every window has been assigned
-        HIPCHK(hipEventRecord(aux.done, su));
-        HIPCHK(hipStreamWaitEvent(st, aux.done, 0));
-        HIPCHK(hipMemcpyAsync(cd.cb, acc.p, (size_t)lanes * sizeof(float), hipMemcpyDeviceToDevice, st));
-        if (h_loss && it == n_iterations - 1) {
+        if (s_enc != s_upd) {
+            HIPCHK(hipEventRecord(aux.done, s_upd));
+            HIPCHK(hipStreamWaitEvent(s_enc, aux.done, 0));
+        }
+        HIPCHK(hipMemcpyAsync(cd.cb, acc.p, (size_t)lanes * sizeof(float), hipMemcpyDeviceToDevice, s_enc));
+        if (with_loss) {
             if (code_bytes == 1)
-                hipLaunchKernelGGL((k_km_loss<uint8_t>), dim3((unsigned)M), dim3(256), 0, st, d_x, x_rs, n,
+                hipLaunchKernelGGL((k_km_loss<uint8_t>), dim3((unsigned)M), dim3(256), 0, s_enc, d_x, x_rs, n,
                                    (const uint8_t*)codes.p, M, cd.cb, (int)K, (int)dsub, len_f, (float*)loss.p);
             else
-                hipLaunchKernelGGL((k_km_loss<uint32_t>), dim3((unsigned)M), dim3(256), 0, st, d_x, x_rs, n,
+                hipLaunchKernelGGL((k_km_loss<uint32_t>), dim3((unsigned)M), dim3(256), 0, s_enc, d_x, x_rs, n,
                                    (const uint32_t*)codes.p, M, cd.cb, (int)K, (int)dsub, len_f, (float*)loss.p);
         }
         HIPCHK(hipGetLastError());
-        bool ok = true;
-        PQCHK(prepare_codebook_dev(cb, slot, st, &ok));  // also the per-iteration synchronisation point
-        cb->norms_ok = ok;
+        if (host_prep) {
+            bool ok = true;
+            PQCHK(prepare_codebook_dev(cb, slot, s_enc, &ok));  // also the per-iteration synchronisation point
+            cb->norms_ok = ok;
+        } else {
+            PQCHK(prepare_codebook_async(cb, slot, s_enc));
+        }
+        return PQHIP_OK;
+    };
+
+    // Small training sets are launch-bound (a dozen short kernels and a host sync per iteration):
+    // all iterations but the last are one captured hipGraph replayed on the internal stream.  The
+    // finite-norm decision stays on the device inside the graph (bad_flag).  Any failure to capture
+    // or instantiate falls back to the eager loop below, which has not run anything yet.
+    int it0 = 0;
+    const bool try_graph = nwin == 1 && cb->groups == 1 && cb->T != 0 && cb->variant != 1 && n_iterations >= 3 &&
+                           n <= (1 << 20) && !getenv("PQHIP_DEBUG_KM_NOGRAPH");
+    if (try_graph) {
+        HIPCHK(hipEventRecord(aux.done, st));            // the instances and the codebook are ready on st
+        HIPCHK(hipStreamWaitEvent(su, aux.done, 0));
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(su, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int32_t rc = iteration(su, su, cd.err + 1, false, false);
+            const hipError_t e = hipStreamEndCapture(su, &graph);
+            ok = rc == PQHIP_OK && e == hipSuccess && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        int32_t status = PQHIP_OK;
+        if (ok) {
+            const int ng = n_iterations - 1;
+            for (int i = 0; i < ng; ++i)
+                if (hipGraphLaunch(exec, su) != hipSuccess) { status = PQHIP_EHIP; g_hip_err = "hipGraphLaunch (k-means iteration)"; break; }
+            if (status == PQHIP_OK) {
+                int bad = 0;
+                if (hipMemcpyAsync(&bad, cd.err + 1, sizeof(int), hipMemcpyDeviceToHost, su) != hipSuccess ||
+                    hipStreamSynchronize(su) != hipSuccess) { status = PQHIP_EHIP; g_hip_err = "k-means graph: flag readback"; }
+                cb->norms_ok = bad == 0;
+                it0 = ng;
+            }
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (status != PQHIP_OK) return status;
+        // su is synchronised (or untouched): st continues in order
     }
+    for (int it = it0; it < n_iterations; ++it)
+        PQCHK(iteration(st, su, nullptr, h_loss && it == n_iterations - 1, true));
     if (h_loss && n_iterations > 0) {
         HIPCHK(hipMemcpyAsync(h_loss, loss.p, (size_t)M * sizeof(float), hipMemcpyDeviceToHost, st));
     }

@@ -760,6 +760,25 @@ def test_kmeans_special_values_and_empty_clusters(ra):
     assert np.isnan(want_loss).any()
     one_q, _ = ra.kmeans_iterations(q0, x, n_iterations=1)
     assert (one_q[0, 5] == 0).all()
+    # >= 3 iterations replay a captured graph: the non-finite centroids that appear after the first
+    # update are then handled through the device-side flag, not by the host switching kernels
+    want_q4, want_loss4 = orc.kmeans_iterations(q0, x, n_iterations=5)
+    got_q4, got_loss4 = ra.kmeans_iterations(q0, x, n_iterations=5)
+    assert got_q4.tobytes() == want_q4.tobytes() and got_loss4.tobytes() == want_loss4.tobytes()
+
+
+def test_kmeans_graph_replay_equals_eager_loop(ra, monkeypatch):
+    """Small training sets run all iterations but the last as one replayed hipGraph: same bits as
+    the eager loop (PQHIP_DEBUG_KM_NOGRAPH) and as the oracle, for u8 and for odd shapes."""
+    for (n, M, K, dsub, iters) in [(4000, 15, 256, 20, 12), (777, 3, 5, 7, 6), (2000, 2, 16, 40, 4)]:
+        q0, x = _km_inputs(n, M, K, dsub, 2200 + n)
+        want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=iters, n_threads=8)
+        got_q, got_loss = ra.kmeans_iterations(q0, x, n_iterations=iters)
+        assert got_q.tobytes() == want_q.tobytes() and got_loss.tobytes() == want_loss.tobytes()
+        monkeypatch.setenv("PQHIP_DEBUG_KM_NOGRAPH", "1")
+        eager_q, eager_loss = ra.kmeans_iterations(q0, x, n_iterations=iters)
+        monkeypatch.delenv("PQHIP_DEBUG_KM_NOGRAPH")
+        assert eager_q.tobytes() == want_q.tobytes() and eager_loss.tobytes() == want_loss.tobytes()
 
 
 def test_kmeans_device_resident_strided_and_at_scale(ra):
