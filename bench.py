@@ -10,8 +10,19 @@ A "step" is one pass of the hot path over one batch: rows_per_gpu synthetic fp32
 in HBM -> u8 codes in HBM.  With N > 1 every rank owns an independent row shard (the path has no
 exchange step: no collective on the data path, "weak" scaling); the only collectives are the
 barrier and the max-reduction of the elapsed time.  Rank 0 prints ONE JSON line.
+
+The default single-GPU run times the headline (BASELINE.json configs[1]) exactly as the contract
+says and then, in the same process and the same JSON line (key "configs"), the other single-GPU
+BASELINE configs with their own roofline / cpu_baseline / parity records:
+    configs[2]  Opq rotate+encode 10 M x 300          (--workload opq_encode)
+    configs[3]  Pq::reconstruct_batch 100 M codes      (--workload reconstruct --rows 100000000)
+    configs[4]  one GPU's shard (12.5 M rows) of the 100 M x 768, M=48 encode  (--workload encode_d768)
+`--no-sub-configs` skips them; `--workload X` runs X alone as the top-level record.
+`--in-process N` instead drives the LIBRARY's own sharder (pqhip_ctx_create(devices) +
+pqhip_quantize_batch_f32 over one host batch, codes concatenated host-side: north_star's form).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,30 +32,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-D, M, K = 300, 15, 256            # BASELINE.json metric: d=300, M=15, K=256
-DSUB = D // M
-FLOP_PER_VEC = 2 * K * D          # distance GEMM only: 153,600
-BYTES_PER_VEC = 4 * D + M         # algorithmic HBM bytes per vector: 1,215
-
-
-def set_shape(d, m, k=256):
-    """non-headline shapes (e.g. BASELINE configs[4]: d=768, M=48) for exploration runs"""
-    global D, M, K, DSUB, FLOP_PER_VEC, BYTES_PER_VEC
-    D, M, K = d, m, k
-    DSUB = D // M
-    FLOP_PER_VEC = 2 * K * D
-    BYTES_PER_VEC = 4 * D + M
-
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
+# workload -> (label, default shape (d, M, K), default rows per GPU)
 WORKLOADS = {
-    "encode": "Pq::quantize_batch {rows} x d=300 fp32 per GPU, M=15, K=256 (BASELINE configs[1]: 10M on 1 MI355X)",
-    "opq_encode": "Opq rotate+encode {rows} x d=300 per GPU, M=15, K=256 (BASELINE configs[2])",
-    "reconstruct": "Pq::reconstruct_batch {rows} u8 codes -> d=300 fp32 per GPU (BASELINE configs[3])",
-    "lookup": "embedding lookup: {rows} random rows of a resident 10M x 15 u8 code matrix -> select + reconstruct + per-row rescale, d=300 fp32 (SURVEY 8f rank 2)",
-    "opq_train": "device part of Opq::train_iteration (rotate, k-means update, quantize->reconstruct, X^T.R), {rows} x d=300 per GPU, M=15, K=256",
-    "kmeans": "kmeans_iteration on all 15 subquantizers (training step; SURVEY 8f rank 1), {rows} x d=300 per GPU, K=256",
+    "encode": ("Pq::quantize_batch {rows} x d={d} fp32 per GPU, M={m}, K={k} (BASELINE configs[1]: 10M on 1 MI355X)", (300, 15, 256), 10_000_000),
+    "opq_encode": ("Opq rotate+encode {rows} x d={d} per GPU, M={m}, K={k} (BASELINE configs[2])", (300, 15, 256), 10_000_000),
+    "reconstruct": ("Pq::reconstruct_batch {rows} u8 codes -> d={d} fp32 per GPU (BASELINE configs[3]: 100M codes on 1 MI355X)", (300, 15, 256), 10_000_000),
+    "encode_d768": ("Pq encode {rows} x d={d} per GPU, M={m}, K={k}: one GPU's shard of BASELINE configs[4] (100M x d=768, M=48 batch-sharded across 8 MI355X = 12.5M rows per GPU)", (768, 48, 256), 12_500_000),
+    "lookup": ("embedding lookup: {rows} random rows of a resident 10M x {m} u8 code matrix -> select + reconstruct + per-row rescale, d={d} fp32 (SURVEY 8f rank 2)", (300, 15, 256), 10_000_000),
+    "adc_scan": ("asymmetric-distance scan: {rows} resident u8 code rows (M={m}) against the K={k}-entry lookup tables of one query, d={d} (SURVEY 8f rank 4)", (300, 15, 256), 100_000_000),
+    "opq_train": ("device part of Opq::train_iteration (rotate, k-means update, quantize->reconstruct, X^T.R), {rows} x d={d} per GPU, M={m}, K={k}", (300, 15, 256), 10_000_000),
+    "kmeans": ("kmeans_iteration on all {m} subquantizers (training step; SURVEY 8f rank 1), {rows} x d={d} per GPU, K={k}", (300, 15, 256), 10_000_000),
 }
 
 
@@ -53,18 +53,23 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the workload's BASELINE size)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="encode")
-    ap.add_argument("--d", type=int, default=300)
-    ap.add_argument("--m", type=int, default=15)
-    ap.add_argument("--k", type=int, default=256, help="centroids per subquantizer (u8 codes up to 256, 32-bit codes beyond)")
+    ap.add_argument("--d", type=int, default=None)
+    ap.add_argument("--m", type=int, default=None)
+    ap.add_argument("--k", type=int, default=None, help="centroids per subquantizer (u8 codes up to 256, 32-bit codes beyond)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 anchor kernel, 2 MFMA kernel")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-configs", action="store_true",
+                    help="headline only: skip the configs[2..4] sub-records of the default run")
+    ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of every sub-config")
+    ap.add_argument("--in-process", type=int, default=0, metavar="N",
+                    help="drive the library's own row sharder over N device slots from ONE process and one host batch")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for the barrier / max-reduction (gloo: rehearsals)")
     ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+                    help="rehearsal on a one-GPU box: every rank / slot uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise sharding/reduction/printing only (CPU, gloo); no GPU work")
     return ap.parse_args()
@@ -75,23 +80,235 @@ def shard_ranges(world, rows):
     return [[r * rows, (r + 1) * rows] for r in range(world)]
 
 
-def load_pmc_traffic(workload, rows):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if they were
-    collected for exactly this workload size; else None."""
+def source_hash():
+    """sha256 over the kernel / C-ABI sources: identifies the build a PMC pass was taken on
+    (.git does not travel to the GPU box, so a commit id is not available there)."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "reductive_amd", "csrc")
+    for name in sorted(os.listdir(base)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(base, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_traffic(workload, rows, d, m, k):
+    """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3 --pmc
+    passes (profiles/pmc_traffic.json, written by tools/pmc_summarize.py).  Refused (None + reason)
+    unless the record was taken for exactly this workload size AND on the kernel sources of this build."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        rec = json.load(open(p)).get(workload)
-        if rec and int(rec["rows"]) == rows:
-            return rec["hbm_bytes_per_launch"]
+        rec = json.load(open(p))["entries"].get("%s@%d@d%d_m%d_k%d" % (workload, rows, d, m, k))
     except Exception:
-        pass
-    return None
+        return None, "no profiles/pmc_traffic.json"
+    if not rec:
+        return None, "no PMC pass for this workload size"
+    if rec.get("source_hash") != source_hash():
+        return None, "stale: PMC pass taken on kernel sources %s, this build is %s" % (rec.get("source_hash"), source_hash())
+    return rec, None
+
+
+class Bench:
+    """One GPU's view of the benchmark: the workloads share the context, the clock helpers and the
+    barrier; every workload returns a self-contained record (value, roofline, cpu_baseline, parity)."""
+
+    def __init__(self, args, rank, world, local_rank, barrier):
+        import torch
+        import reductive_amd
+        from reductive_amd.pq import _Ctx
+        self.args, self.rank, self.world, self.barrier = args, rank, world, barrier
+        self.torch = torch
+        self.ra = reductive_amd
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        reductive_amd.lib()                       # fails loudly if the HIP library is missing
+        self.ctx = _Ctx(devices=[local_rank])     # one process per GPU
+
+    # ---- timing: K steps between barrier + synchronize pairs; HIP events per step on the launch stream
+    def timed(self, step, steps, warmup):
+        torch = self.torch
+        for _ in range(warmup):
+            step()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()                            # torch's current stream = the stream passed to the C ABI
+            step()
+            b.record()
+        torch.cuda.synchronize()
+        self.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        per = [a.elapsed_time(b) for a, b in evs]
+        return elapsed, sum(per) / len(per), min(per), max(per)
+
+    def normal_rows(self, rows, d, seed):
+        torch = self.torch
+        g = torch.Generator(device=self.dev).manual_seed(seed)
+        src = torch.empty((rows, d), device=self.dev, dtype=torch.float32)
+        for r0 in range(0, rows, 1 << 20):        # N(0,1) like benches/pq.rs:9, generated in HBM
+            src[r0:r0 + (1 << 20)].normal_(generator=g)
+        return src
+
+    def run(self, workload, rows, d, m, k, steps, warmup, cpu=True):
+        import numpy as np
+        import synth
+        torch, args = self.torch, self.args
+        dsub = d // m
+        flop_enc = 2 * k * d                      # distance GEMM only (SURVEY.md 8d)
+        bytes_vec = 4 * d + m                     # algorithmic HBM bytes per vector
+        q = synth.normalish(43, (m, k, dsub))     # same codebook on every rank (replicated)
+        P = synth.orthonormal(44, d) if workload == "opq_encode" else None
+        pq = self.ra.Pq(P, q, ctx=self.ctx)
+        if args.variant:
+            pq.set_encode_variant(args.variant)
+        g = torch.Generator(device=self.dev).manual_seed(42 + self.rank)
+        extra, cpu_rec, q0 = {}, None, None
+        kernel = None
+        if workload == "reconstruct":
+            src = torch.randint(0, k, (rows, m), device=self.dev, dtype=torch.uint8, generator=g)
+            dst = torch.empty((rows, d), device=self.dev, dtype=torch.float32)
+            step = lambda: pq.reconstruct_batch_device(src, out=dst, check=False)
+            kernel = "k_reconstruct"
+        elif workload == "lookup":
+            n_codes = 10_000_000
+            src = torch.randint(0, k, (n_codes, m), device=self.dev, dtype=torch.uint8, generator=g)
+            sel = torch.randint(0, n_codes, (rows,), device=self.dev, dtype=torch.int64, generator=g)
+            scl = torch.rand((n_codes,), device=self.dev, dtype=torch.float32, generator=g) + 0.5
+            dst = torch.empty((rows, d), device=self.dev, dtype=torch.float32)
+            step = lambda: pq.reconstruct_rows_device(src, sel, scales=scl, out=dst, check=False)
+            kernel = "k_reconstruct<.., SEL>"
+        elif workload == "adc_scan":
+            src = torch.randint(0, k, (rows, m), device=self.dev, dtype=torch.uint8, generator=g)
+            query = torch.from_numpy(synth.normalish(45, (d,))).to(self.dev)
+            dst = torch.empty((rows,), device=self.dev, dtype=torch.float32)
+            lut = pq.adc_tables_device(query)
+            step = lambda: pq.adc_scan_device(src, lut, out=dst)
+            kernel = "k_adc_scan"
+        else:
+            src = self.normal_rows(rows, d, 42 + self.rank)
+            dst = torch.empty((rows, m), device=self.dev, dtype=torch.uint8 if k <= 256 else torch.int32)
+            step = lambda: pq.quantize_batch_device(src, out=dst)
+        if workload in ("opq_train", "kmeans"):
+            # initial centroids = K distinct instances per subquantizer (RandomInstanceCentroids, pq.rs:166-172)
+            pick = torch.arange(k, device=self.dev) * (rows // k)
+            q0 = np.stack([src[(pick + 7 * mm) % rows, mm * dsub:(mm + 1) * dsub].cpu().numpy() for mm in range(m)])
+        if workload == "opq_train":
+            from reductive_amd.pq import opq_train_step
+            P0 = synth.orthonormal(44, d)
+            state = {"q": q0}
+
+            def step():
+                state["q"], state["cross"] = opq_train_step(state["q"], P0, src, ctx=self.ctx)
+        if workload == "kmeans":
+            # one step = one kmeans_iteration (assign + update) of all M subquantizers over the resident
+            # instances; the K timed steps are ONE library call with n_iterations = K, exactly how
+            # pq.rs:176 drives it (centroids carried from step to step)
+            from reductive_amd.pq import kmeans_iterations
+
+            def run_steps(n_it):
+                if n_it > 0:
+                    kmeans_iterations(q0, src, n_iterations=n_it, want_loss=False, ctx=self.ctx)
+            run_steps(warmup)
+            torch.cuda.synchronize()
+            self.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(steps)
+            torch.cuda.synchronize()
+            self.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            kernel_ms = kmin = kmax = 1e3 * elapsed / steps
+        else:
+            elapsed, kernel_ms, kmin, kmax = self.timed(step, steps, warmup)
+        if kernel is None:
+            kernel = pq.last_encode_kernel() if workload != "kmeans" else None
+        if kernel:
+            extra["encode_kernel" if workload not in ("reconstruct", "lookup", "adc_scan") else "kernel"] = kernel
+
+        sec = kernel_ms * 1e-3
+        traffic_rec, why = load_pmc_traffic(workload, rows, d, m, k)
+        traffic = traffic_rec["hbm_bytes_per_launch"] if traffic_rec else None
+        if workload in ("reconstruct", "lookup", "adc_scan"):
+            if workload == "lookup":
+                bytes_vec = 4 * d + m + 8 + 4     # output row + code row + row index + scale
+            if workload == "adc_scan":
+                bytes_vec = m + 4                 # code row in, one f32 distance out
+            ach = bytes_vec * rows / sec / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                    "traffic": traffic, "kernel": kernel, "avg_launch_ms": kernel_ms, "min_launch_ms": kmin,
+                    "max_launch_ms": kmax, "worst_launch_frac": bytes_vec * rows / (kmax * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "algorithmic_bytes_per_vector": bytes_vec}
+        else:
+            flop = flop_enc + (2 * d * d if workload == "opq_encode" else 0)
+            if workload == "opq_train":           # rotation + 2 assignments + cross product
+                flop = 2 * d * d + 2 * flop_enc + 2 * d * d
+            ach = flop * rows / sec / 1e12
+            ek = kernel or "k_encode_mfma_lds3"
+            roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                    "kernel": {"encode": ek, "encode_d768": ek, "opq_encode": "k_rotate_pblock5 + " + ek,
+                               "kmeans": "encode kernel + k_km_{hist,scan,scatter,segsum} + codebook prep (whole iteration)",
+                               "opq_train": "k_rotate_pblock5 + 2 x " + ek + " + k_km_* + k_reconstruct + k_atb_blocks/fold (whole step)"}[workload],
+                    "avg_launch_ms": kernel_ms, "min_launch_ms": kmin, "max_launch_ms": kmax,
+                    "algorithmic_flop_per_vector": flop, "algorithmic_bytes_per_vector": bytes_vec,
+                    "hbm_gbs": bytes_vec * rows / sec / 1e9, "hbm_frac": bytes_vec * rows / sec / 1e9 / PEAK_HBM_GBS}
+        if traffic_rec:
+            roof["traffic_kernel"] = traffic_rec.get("kernel")
+            roof["traffic_over_algorithmic"] = traffic / float(bytes_vec * rows)
+        else:
+            roof["traffic_note"] = why
+
+        if cpu and self.world == 1 and not args.no_cpu_baseline:
+            if workload in ("encode", "opq_encode", "encode_d768"):
+                cpu_rec = cpu_baseline(args, q, P, src, dst, pq, full=(workload == "encode"))
+            elif workload == "reconstruct":
+                cpu_rec = cpu_baseline_reconstruct(q, src, dst)
+            elif workload == "kmeans":
+                cpu_rec = cpu_baseline_kmeans(args, q0, src, self.ctx)
+            elif workload == "adc_scan":
+                cpu_rec = cpu_baseline_adc(q, query, src, dst, lut)
+        del src, dst
+        pq.close()
+        torch.cuda.empty_cache()
+        return {"elapsed": elapsed, "rows": rows, "steps": steps, "warmup": warmup, "extra": extra,
+                "roofline": roof, "cpu_baseline": cpu_rec, "shape": (d, m, k)}
+
+
+METRIC_NAMES = {"encode": "vectors/sec PQ encode", "encode_d768": "vectors/sec PQ encode",
+                "opq_encode": "vectors/sec OPQ rotate+encode", "reconstruct": "vectors/sec PQ reconstruct",
+                "lookup": "vectors/sec select+reconstruct+rescale lookup",
+                "adc_scan": "codes/sec asymmetric-distance scan",
+                "opq_train": "vectors/sec per OPQ training iteration (device part)",
+                "kmeans": "vectors/sec per k-means iteration, all subquantizers"}
+
+
+def record(workload, r, world, shards=None):
+    d, m, k = r["shape"]
+    total_rows = world * r["rows"]
+    rec = {"metric": "%s (d=%d, M=%d, K=%d)" % (METRIC_NAMES[workload], d, m, k),
+           "value": total_rows * r["steps"] / r["elapsed"], "unit": "vectors/s",
+           "n_gpus": world, "steps": r["steps"], "warmup": r["warmup"],
+           "ms_per_step": 1e3 * r["elapsed"] / r["steps"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": WORKLOADS[workload][0].format(rows=r["rows"], d=d, m=m, k=k),
+                      "rows_per_gpu": r["rows"], "rows_total": total_rows, "d": d, "M": m, "K": k,
+                      "placement": "inputs and outputs resident in HBM; C ABI device entry point"}}
+    if shards is not None:
+        rec["config"]["shards"] = shards
+    rec.update(r["extra"])
+    rec["roofline"] = r["roofline"]
+    if r["cpu_baseline"] is not None:
+        rec["cpu_baseline"] = r["cpu_baseline"]
+    return rec
 
 
 def main():
     args = parse()
-    if (args.d, args.m, args.k) != (300, 15, 256):
-        set_shape(args.d, args.m, args.k)
     import torch
     import torch.distributed as dist
 
@@ -104,110 +321,29 @@ def main():
         dist.init_process_group(backend=args.backend if use_gpu else "gloo", rank=rank, world_size=world)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    rows = args.rows
+    label, (d0, m0, k0), rows0 = WORKLOADS[args.workload]
+    d, m, k = args.d or d0, args.m or m0, args.k or k0
+    rows = args.rows or rows0
     shards = shard_ranges(world, rows)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    kernel_ms = None
-    extra = {}
-    q0 = None
+    if args.in_process:
+        if world != 1:
+            raise SystemExit("--in-process drives all device slots from ONE process")
+        print(json.dumps(in_process(args, d, m, k, rows)), flush=True)
+        return
+
     if use_gpu:
-        import numpy as np
-        import reductive_amd
-        import synth
         if args.single_device:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
-        reductive_amd.lib()                       # fails loudly if the HIP library is missing
-        from reductive_amd.pq import _Ctx
-        ctx = _Ctx(devices=[local_rank])          # one process per GPU
-        q = synth.normalish(43, (M, K, DSUB))     # same codebook on every rank (replicated)
-        P = synth.orthonormal(44, D) if args.workload == "opq_encode" else None
-        pq = reductive_amd.Pq(P, q, ctx=ctx)
-        if args.variant:
-            pq.set_encode_variant(args.variant)
-        g = torch.Generator(device=dev).manual_seed(42 + rank)
-        if args.workload == "reconstruct":
-            src = torch.randint(0, K, (rows, M), device=dev, dtype=torch.uint8, generator=g)
-            dst = torch.empty((rows, D), device=dev, dtype=torch.float32)
-
-            def step():
-                pq.reconstruct_batch_device(src, out=dst)
-        elif args.workload == "lookup":
-            n_codes = 10_000_000
-            src = torch.randint(0, K, (n_codes, M), device=dev, dtype=torch.uint8, generator=g)
-            sel = torch.randint(0, n_codes, (rows,), device=dev, dtype=torch.int64, generator=g)
-            scl = torch.rand((n_codes,), device=dev, dtype=torch.float32, generator=g) + 0.5
-            dst = torch.empty((rows, D), device=dev, dtype=torch.float32)
-
-            def step():
-                pq.reconstruct_rows_device(src, sel, scales=scl, out=dst)
-        else:
-            src = torch.empty((rows, D), device=dev, dtype=torch.float32)
-            for r0 in range(0, rows, 1 << 20):    # N(0,1) like benches/pq.rs:9, generated in HBM
-                src[r0:r0 + (1 << 20)].normal_(generator=g)
-            dst = torch.empty((rows, M), device=dev, dtype=torch.uint8 if K <= 256 else torch.int32)
-
-            def step():
-                pq.quantize_batch_device(src, out=dst)
-        if args.workload == "opq_train":
-            from reductive_amd.pq import opq_train_step
-            P0 = synth.orthonormal(44, D)
-            pick = torch.arange(K, device=dev) * (rows // K)
-            q0 = np.stack([src[(pick + 7 * m) % rows, m * DSUB:(m + 1) * DSUB].cpu().numpy() for m in range(M)])
-            state = {"q": q0}
-
-            def step():
-                state["q"], state["cross"] = opq_train_step(state["q"], P0, src, ctx=ctx)
-        if args.workload == "kmeans":
-            # one step = one kmeans_iteration (assign + update) of all M subquantizers over the
-            # resident instances; the K timed steps are ONE library call with n_iterations = K,
-            # exactly how pq.rs:176 drives it (centroids carried from step to step)
-            from reductive_amd.pq import kmeans_iterations
-            # initial centroids = K distinct instances per subquantizer (RandomInstanceCentroids, pq.rs:166-172)
-            pick = torch.arange(K, device=dev) * (rows // K)
-            q0 = np.stack([src[(pick + 7 * m) % rows, m * DSUB:(m + 1) * DSUB].cpu().numpy() for m in range(M)])
-
-            def run_steps(k):
-                if k > 0:
-                    kmeans_iterations(q0, src, n_iterations=k, want_loss=False, ctx=ctx)
-            run_steps(args.warmup)
-            torch.cuda.synchronize()
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run_steps(args.steps)
-            torch.cuda.synchronize()
-            barrier()
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
-            kernel_ms = 1e3 * elapsed / args.steps
-            extra["encode_kernel"] = "k_encode_mfma_lds3<vec4>"
-            step = None
-        for _ in range(args.warmup if step else 0):
-            step()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-               for _ in range(args.steps)]
-        if step:
-            torch.cuda.synchronize()
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for a, b in evs:
-                a.record()                        # same stream the kernels are launched on
-                step()
-                b.record()
-            torch.cuda.synchronize()
-            barrier()
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
-            kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
-            extra["encode_kernel"] = pq.last_encode_kernel() if args.workload not in ("reconstruct", "lookup") else "k_reconstruct"
+        b = Bench(args, rank, world, local_rank, barrier)
+        main_r = b.run(args.workload, rows, d, m, k, args.steps, args.warmup)
+        elapsed = main_r["elapsed"]
     else:
+        main_r = None
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -222,90 +358,108 @@ def main():
     elapsed = float(tmax.item())
 
     if rank == 0:
-        total_rows = world * rows
-        value = total_rows * args.steps / elapsed
-        shape = "(d=%d, M=%d, K=%d)" % (D, M, K)
-        names = {"encode": "vectors/sec PQ encode " + shape,
-                 "opq_encode": "vectors/sec OPQ rotate+encode " + shape,
-                 "reconstruct": "vectors/sec PQ reconstruct " + shape,
-                 "lookup": "vectors/sec select+reconstruct+rescale lookup " + shape,
-                 "opq_train": "vectors/sec per OPQ training iteration (device part) " + shape,
-                 "kmeans": "vectors/sec per k-means iteration, all subquantizers " + shape}
-        rec = {
-            "metric": names[args.workload], "value": value, "unit": "vectors/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload].format(rows=rows) if (D, M, K) == (300, 15, 256) else
-                       "%s, non-headline shape d=%d M=%d K=%d" % (args.workload, D, M, K), "rows_per_gpu": rows,
-                       "rows_total": total_rows, "d": D, "M": M, "K": K, "shards": shards,
-                       "placement": "inputs and outputs resident in HBM; C ABI device entry point"},
-        }
-        rec.update(extra)
-        if use_gpu:
-            sec = kernel_ms * 1e-3
-            traffic = load_pmc_traffic(args.workload, rows)
-            if args.workload in ("reconstruct", "lookup"):
-                if args.workload == "lookup":
-                    global BYTES_PER_VEC
-                    BYTES_PER_VEC = 4 * D + M + 8 + 4     # output row + code row + row index + scale
-                ach = BYTES_PER_VEC * rows / sec / 1e9
-                rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
-                                   "kernel": "k_reconstruct" + ("<.., SEL>" if args.workload == "lookup" else ""), "avg_launch_ms": kernel_ms,
-                                   "algorithmic_bytes_per_vector": BYTES_PER_VEC}
-            else:
-                flop = FLOP_PER_VEC + (2 * D * D if args.workload == "opq_encode" else 0)
-                if args.workload == "opq_train":   # rotation + 2 assignments + cross product
-                    flop = 2 * D * D + 2 * FLOP_PER_VEC + 2 * D * D
-                ach = flop * rows / sec / 1e12
-                rec["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                                   "kernel": {"encode": extra["encode_kernel"], "opq_encode": "k_rotate_pblock5 + " + extra["encode_kernel"],
-                                              "kmeans": extra["encode_kernel"] + " + k_km_{hist,scan,scatter,segsum} + codebook prep (whole iteration)",
-                                              "opq_train": "k_rotate_pblock5 + 2 x " + extra["encode_kernel"] + " + k_km_* + k_reconstruct + k_atb_blocks/fold (whole step)"}[args.workload],
-                                   "avg_launch_ms": kernel_ms, "algorithmic_flop_per_vector": flop,
-                                   "algorithmic_bytes_per_vector": BYTES_PER_VEC,
-                                   "hbm_gbs": BYTES_PER_VEC * rows / sec / 1e9,
-                                   "hbm_frac": BYTES_PER_VEC * rows / sec / 1e9 / PEAK_HBM_GBS}
-            if world == 1 and not args.no_cpu_baseline and args.workload in ("encode", "opq_encode"):
-                rec["cpu_baseline"] = cpu_baseline(args, q, P, src, dst, pq)
-            if world == 1 and not args.no_cpu_baseline and args.workload == "reconstruct":
-                # BASELINE.md B-rec: the oracle's gather (primitives.rs:110-173 semantics, single thread as in
-                # the reference) on the first 1 M codes, and the GPU rows checked against it byte for byte
-                from oracle import pq_oracle as orc
-                n_s = min(1_000_000, rows)
-                c_host = src[:n_s].cpu().numpy()
-                t = time.perf_counter()
-                want = orc.reconstruct_batch(q, c_host)
-                t_cpu = time.perf_counter() - t
-                rec["cpu_baseline"] = {"value": n_s / t_cpu, "unit": "vectors/s", "cores": 1, "kind": "port",
-                                       "sample": "first %d code rows of the bench batch, oracle gather on one thread (%.1f s)" % (n_s, t_cpu),
-                                       "gpu_rows_identical_on_sample": bool(dst[:n_s].cpu().numpy().tobytes() == want.tobytes())}
-            if world == 1 and not args.no_cpu_baseline and args.workload == "kmeans":
-                rec["cpu_baseline"] = cpu_baseline_kmeans(args, q0, src, ctx)
+        if main_r is None:
+            main_r = {"elapsed": elapsed, "rows": rows, "steps": args.steps, "warmup": args.warmup, "extra": {},
+                      "roofline": None, "cpu_baseline": None, "shape": (d, m, k)}
+        main_r["elapsed"] = elapsed               # max over ranks
+        rec = record(args.workload, main_r, world, shards)
+        if not use_gpu:
+            rec.pop("roofline", None)
+        # the other single-GPU BASELINE configs, each with its own roofline / cpu_baseline / parity record
+        default_headline = (args.workload == "encode" and (d, m, k) == (300, 15, 256) and rows == 10_000_000)
+        if use_gpu and world == 1 and default_headline and not args.no_sub_configs:
+            subs = {}
+            for key, wl, srows in (("configs[2]", "opq_encode", 10_000_000),
+                                   ("configs[3]", "reconstruct", 100_000_000),
+                                   ("configs[4]_one_gpu_shard", "encode_d768", 12_500_000)):
+                sd, sm, sk = WORKLOADS[wl][1]
+                try:
+                    r = b.run(wl, srows, sd, sm, sk, max(1, min(args.steps, args.sub_steps)), 1)
+                    subs[key] = record(wl, r, 1)
+                except Exception as e:            # a sub-config must never take the headline line down
+                    subs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            rec["configs"] = subs
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, q, P, src, dst, pq):
+def in_process(args, d, m, k, rows):
+    """north_star's multi-GPU form, measured through the LIBRARY's sharder: one process, one host batch,
+    pqhip_ctx_create(devices) + pqhip_quantize_batch_f32 (contiguous row shards, one host thread per
+    device, codebook replicated, no collective, codes land in one host array).  PCIe-inclusive by
+    construction, so this is reported beside -- never as -- the HBM-resident `value` of the default run."""
+    import numpy as np
+    import reductive_amd
+    import synth
+    from reductive_amd.pq import _Ctx
+    n_slots = args.in_process
+    devices = [0] * n_slots if args.single_device else list(range(n_slots))
+    reductive_amd.lib()
+    ctx = _Ctx(devices=devices)
+    q = synth.normalish(43, (m, k, d // m))
+    pq = reductive_amd.Pq(None, q, ctx=ctx)
+    rng = np.random.default_rng(42)
+    x = rng.standard_normal((rows, d), dtype=np.float32)
+    out = np.empty((rows, m), np.uint8 if k <= 256 else np.uint32)
+    for _ in range(max(1, args.warmup)):
+        pq.quantize_batch_into(x[:min(rows, 262144)], out[:min(rows, 262144)])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pq.quantize_batch_into(x, out)
+    elapsed = time.perf_counter() - t0
+    per = (rows + n_slots - 1) // n_slots
+    rec = {"metric": "vectors/sec PQ encode, host-resident batch through the library's device sharder (d=%d, M=%d, K=%d)" % (d, m, k),
+           "value": rows * args.steps / elapsed, "unit": "vectors/s", "n_gpus": n_slots, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "pqhip_quantize_batch_f32 over ONE host batch of %d x %d, rows sharded contiguously over %d device slot(s) %s, codes concatenated host-side (PCIe-inclusive)"
+                                  % (rows, d, n_slots, devices), "rows_total": rows, "d": d, "M": m, "K": k,
+                      "shards": [[i * per, min(rows, (i + 1) * per)] for i in range(n_slots)],
+                      "placement": "inputs and outputs in pageable host memory"},
+           "host_gbs": rows * (4 * d + m) * args.steps / elapsed / 1e9}
+    if not args.no_cpu_baseline:
+        from oracle import pq_oracle as orc
+        n_s = min(rows, 200_000)
+        tail = slice(rows - n_s, rows)
+        rec["codes_identical_to_oracle_head_and_tail"] = bool(
+            (orc.quantize_batch(q, x[:n_s], n_threads=os.cpu_count() or 1) == out[:n_s]).all()
+            and (orc.quantize_batch(q, x[tail], n_threads=os.cpu_count() or 1) == out[tail]).all())
+    return rec
+
+
+def cpu_baseline(args, q, P, src, dst, pq, full=True):
     """The oracle (a C port of the reference's path, CANON-F32) timed on this box's host cores on
     a bounded sample of the SAME workload, plus a parity check of the GPU codes on that sample.
     The oracle is used here only as the thing timed/checked -- never as the product."""
     from oracle import pq_oracle as orc
+    import numpy as np
     cores = os.cpu_count() or 1
-    n_mt = min(args.cpu_rows, src.shape[0])
-    n_st = min(max(n_mt // 8, 1), 250_000)
+    d = src.shape[1]
+    scale = max(1, (d * (2 if P is not None else 1)) // 300)      # keep the sample's CPU work bounded for wide / OPQ shapes
+    n_mt = min(args.cpu_rows // scale, src.shape[0])
+    n_st = min(max(n_mt // 8, 1), 250_000 // scale)
     x = src[:n_mt].cpu().numpy()
     t = time.perf_counter()
-    c_mt = orc.quantize_batch(q, x, projection=P, n_threads=cores)
+    c_mt = orc.quantize_batch(q, x, projection=P, n_threads=cores, dtype=np.uint8 if dst.dtype.itemsize == 1 else np.uint32)
     t_mt = time.perf_counter() - t
     t = time.perf_counter()
     orc.quantize_batch(q, x[:n_st], projection=P, n_threads=1)
     t_st = time.perf_counter() - t
-    same = bool((dst[:n_mt].cpu().numpy() == c_mt).all())
+    same = bool((dst[:n_mt].cpu().numpy().astype(np.int64) == c_mt.astype(np.int64)).all())
+    # the sample's tail of the batch as well (last rows of the launch: ragged row groups, clamped tiles)
+    n_tail = min(200_000 // scale, src.shape[0])
+    xt = src[-n_tail:].cpu().numpy()
+    same_tail = bool((dst[-n_tail:].cpu().numpy().astype(np.int64) ==
+                      orc.quantize_batch(q, xt, projection=P, n_threads=cores, dtype=np.uint32).astype(np.int64)).all())
+    rec = {"value": n_mt / t_mt, "unit": "vectors/s", "cores": cores, "kind": "port",
+           "sample": "first %d rows of the bench batch, oracle sharded over %d threads (%.1f s); "
+                     "single-thread: %d rows; parity also on the last %d rows" % (n_mt, cores, t_mt, n_st, n_tail),
+           "single_thread_value": n_st / t_st, "simd": "avx2+fma" if orc.lib().pqo_uses_fma_simd() else "scalar",
+           "gpu_codes_identical_on_sample": same and same_tail}
+    if not full:
+        return rec
     # PCIe-inclusive rate of the host-buffer entry point on the same sample (never `value`)
     n_h = min(n_mt, 1_000_000)
     pq.quantize_batch(x[:65536])
@@ -317,7 +471,6 @@ def cpu_baseline(args, q, P, src, dst, pq):
     blas = None
     if P is None:
         try:
-            import numpy as np
             n_b = min(n_mt, 200_000)
             xb = x[:n_b]
             cc = (q.astype(np.float32) ** 2).sum(-1)
@@ -331,14 +484,33 @@ def cpu_baseline(args, q, P, src, dst, pq):
                     "agreement_with_canon": float((codes_b == c_mt[:n_b]).mean())}
         except Exception:
             blas = None
-    return {"value": n_mt / t_mt, "unit": "vectors/s", "cores": cores, "kind": "port",
-            "blas_formulation": blas,
-            "sample": "first %d rows of the bench batch, oracle sharded over %d threads (%.1f s); "
-                      "single-thread: %d rows" % (n_mt, cores, t_mt, n_st),
-            "single_thread_value": n_st / t_st, "simd": "avx2+fma" if orc.lib().pqo_uses_fma_simd() else "scalar",
-            "gpu_codes_identical_on_sample": same,
-            "host_resident_api_value": n_h / t_h,
-            "host_resident_api_identical": bool((c_h == c_mt[:n_h]).all())}
+    rec.update({"blas_formulation": blas, "host_resident_api_value": n_h / t_h,
+                "host_resident_api_gbs": n_h * (4 * d + q.shape[0]) / t_h / 1e9,
+                "host_resident_api_identical": bool((c_h == c_mt[:n_h]).all())})
+    return rec
+
+
+def cpu_baseline_reconstruct(q, src, dst):
+    """BASELINE.md B-rec: the oracle's gather (primitives.rs:110-173 semantics, single thread as in the
+    reference) on head, middle and TAIL row ranges of the launch -- for the 100 M-code config the tail
+    rows sit beyond element offset 2^32 of the output and beyond the Infinity Cache's reach of the code
+    matrix -- and the GPU rows checked against it byte for byte."""
+    from oracle import pq_oracle as orc
+    rows = src.shape[0]
+    n_s = min(250_000, rows)
+    starts = sorted({0, max(0, rows // 2 - n_s // 2), max(0, rows - n_s)})
+    t_cpu, ok, n_tot = 0.0, True, 0
+    for s0 in starts:
+        c_host = src[s0:s0 + n_s].cpu().numpy()
+        t = time.perf_counter()
+        want = orc.reconstruct_batch(q, c_host)
+        t_cpu += time.perf_counter() - t
+        n_tot += c_host.shape[0]
+        ok = ok and bool(dst[s0:s0 + n_s].cpu().numpy().tobytes() == want.tobytes())
+    return {"value": n_tot / t_cpu, "unit": "vectors/s", "cores": 1, "kind": "port",
+            "sample": "%d code rows at row offsets %s of the bench batch (head, middle, tail; last output element offset %d), "
+                      "oracle gather on one thread (%.1f s)" % (n_s, starts, rows * q.shape[0] * q.shape[2] - 1, t_cpu),
+            "gpu_rows_identical_on_sample": ok}
 
 
 def cpu_baseline_kmeans(args, q0, src, ctx):
@@ -359,6 +531,28 @@ def cpu_baseline_kmeans(args, q0, src, ctx):
                       "threads, update + loss sequential (%.1f s)" % (n_s, cores, t_cpu),
             "gpu_centroids_identical_on_sample": bool(got_q.tobytes() == want_q.tobytes()),
             "gpu_loss_identical_on_sample": bool(got_loss.tobytes() == want_loss.tobytes())}
+
+
+def cpu_baseline_adc(q, query, src, dst, lut):
+    """The oracle's table build + scan (declared f32 order: tables by CANON-F32 rules 1-3, row sums
+    sequentially over m) on head and tail samples of the code matrix; GPU distances checked bit for bit."""
+    from oracle import pq_oracle as orc
+    rows = src.shape[0]
+    n_s = min(2_000_000, rows)
+    qh = query.cpu().numpy()
+    want_lut = orc.adc_tables(q, qh)
+    ok = bool(lut.cpu().numpy().tobytes() == want_lut.tobytes())
+    t_cpu, n_tot = 0.0, 0
+    for s0 in sorted({0, rows - n_s}):
+        c_host = src[s0:s0 + n_s].cpu().numpy()
+        t = time.perf_counter()
+        want = orc.adc_scan(want_lut, c_host)
+        t_cpu += time.perf_counter() - t
+        n_tot += c_host.shape[0]
+        ok = ok and bool(dst[s0:s0 + n_s].cpu().numpy().tobytes() == want.tobytes())
+    return {"value": n_tot / t_cpu, "unit": "vectors/s", "cores": 1, "kind": "port",
+            "sample": "%d code rows (head and tail of the resident matrix), oracle scan on one thread (%.1f s)" % (n_tot, t_cpu),
+            "gpu_distances_identical_on_sample": ok}
 
 
 if __name__ == "__main__":

@@ -129,6 +129,28 @@ int32_t pqhip_reconstruct_rows_f32_dev(pqhip_codebook *cb, int32_t device_slot, 
                                        const int64_t *d_rows, int64_t n_rows, const float *d_scales,
                                        float *d_out, int64_t out_row_stride, void *stream);
 
+/*
+ * "Next" row: asymmetric distance computation -- the scan that follows
+ * encode in a PQ pipeline, over a code matrix kept resident in HBM.  Not a function of reductive; it
+ * is defined from the reference's own vector-to-matrix distance so that it has an exact meaning:
+ *   tables[q][m][j] = y_q[m*dsub .. (m+1)*dsub).squared_euclidean_distance(quantizers[m])[j]
+ *                     (src/linalg.rs:118-148 -- the distances `kmeans::cluster_assignment`,
+ *                     kmeans.rs:111-126, minimises inside `Pq::quantize_vector`, pq.rs:285-298), with
+ *                     y_q = query_q.dot(projection) first for an OPQ quantizer (pq.rs:293);
+ *                     hence argmin_j tables[q][m][j] == quantize_vector(query_q)[m];
+ *   out[q][i]       = sum over m = 0 .. M-1, in that order, from +0, of tables[q][m][codes[i][m]]
+ *                     (f32 adds; the estimate of |query_q - reconstruct(codes[i])|^2 for plain PQ).
+ * d_queries [n_queries][q_row_stride] f32 and d_tables [n_queries][M][K] f32 live in HBM; d_codes
+ * [n_codes][codes_row_stride] are 1- or 4-byte codes; d_out [n_queries][out_row_stride] f32.
+ * A code >= K raises the stream's range flag (pqhip_check_codes_dev -> PQHIP_ECODE_RANGE).
+ * Both calls are asynchronous on `stream`.
+ */
+int32_t pqhip_adc_tables_f32_dev(pqhip_codebook *cb, int32_t device_slot, const float *d_queries,
+                                 int64_t n_queries, int64_t q_row_stride, float *d_tables, void *stream);
+int32_t pqhip_adc_scan_f32_dev(pqhip_codebook *cb, int32_t device_slot, const float *d_tables,
+                               int64_t n_queries, const void *d_codes, int32_t code_bytes, int64_t n_codes,
+                               int64_t codes_row_stride, float *d_out, int64_t out_row_stride, void *stream);
+
 /* Reconstruct's range check is asynchronous on the device path: returns PQHIP_ECODE_RANGE if any
  * device call since the last query saw a code >= K (synchronises `stream`). */
 int32_t pqhip_check_codes_dev(pqhip_codebook *cb, int32_t device_slot, void *stream);

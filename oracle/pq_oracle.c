@@ -19,6 +19,8 @@
  *   src/kmeans.rs:166-198, 308-360  update_centroids, kmeans_iteration, mean_squared_error
  *   src/pq/opq.rs:156-195      Opq::train_iteration without its LAPACK calls
  *                              ("next" row: the k-means step of PQ/OPQ training)
+ *   pqo_adc_tables / pqo_adc_scan: "next" row rank 4 (asymmetric distance scan over codes), declared
+ *                              from linalg.rs:118-148 -- see the comment at the functions
  *
  * PARITY STATUS.  The reference is Rust and cannot be compiled in this image
  * (no rustc/cargo), so this restatement is pinned by the reference's own
@@ -506,4 +508,67 @@ int pqo_opq_train_step(float *cb, int64_t M, int64_t K, int64_t dsub, const floa
     return rc;
 }
 
-int pqo_abi_version(void) { return 3; }
+/* ---- "next" row: asymmetric distance computation over codes --------
+ * Not a function of reductive itself (it is the step that follows encode in any PQ pipeline); it is
+ * DECLARED here from the reference's own pieces so that it has an exact definition:
+ *   tables[m][j] = y_m.squared_euclidean_distance(quantizers[m])[j]       (linalg.rs:118-148, the very
+ *                  distances kmeans::cluster_assignment minimises at kmeans.rs:111-126), with
+ *                  y = query.dot(P) first when the quantizer has a projection (pq.rs:293);
+ *                  => argmin_j tables[m][j] == quantize_vector(query)[m]   (tested);
+ *   dist[i]      = sum over m = 0..M-1, in order, from +0, of tables[m][codes[i][m]]  (f32 adds,
+ *                  Rust's `Iterator::sum::<f32>()` order).
+ * Parity: unpinned by the reference by construction (no reference lines); the oracle is the definition. */
+int pqo_adc_tables(const float *cb, int64_t M, int64_t K, int64_t dsub, const float *P, const float *y,
+                   float *tables)
+{
+    const int64_t d = M * dsub;
+    float *rx = (float *)malloc(sizeof(float) * (size_t)d);
+    if (P) {
+        for (int64_t c = 0; c < d; ++c) {       /* 1-D x 2-D ndarray dot, as in pqo_quantize_vector */
+            float s = 0.0f;
+            for (int64_t k = 0; k < d; ++k) { float prod = y[k] * P[k * d + c]; s = s + prod; }
+            rx[c] = s;
+        }
+    } else {
+        memcpy(rx, y, sizeof(float) * (size_t)d);
+    }
+    for (int64_t m = 0; m < M; ++m) {
+        const float *xs = rx + m * dsub;
+        float xx = pqo_dot_unrolled(xs, xs, dsub);
+        for (int64_t j = 0; j < K; ++j) {
+            const float *c = cb + (m * K + j) * dsub;
+            float cc = pqo_dot_unrolled(c, c, dsub);
+            float dp = pqo_dot_unrolled(c, xs, dsub);
+            float t = xx + cc;
+            float u = dp + dp;
+            tables[m * K + j] = t - u;
+        }
+    }
+    free(rx);
+    return 0;
+}
+
+/* returns 2 when a code >= K is met (the lookup would index out of bounds) */
+int pqo_adc_scan(const float *tables, int64_t M, int64_t K, const void *codes, int code_bytes, int64_t n,
+                 int64_t c_rs, int64_t c_cs, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float s = 0.0f;
+        for (int64_t m = 0; m < M; ++m) {
+            const int64_t off = i * c_rs + m * c_cs;
+            uint64_t code;
+            switch (code_bytes) {
+            case 1: code = ((const uint8_t *)codes)[off]; break;
+            case 2: code = ((const uint16_t *)codes)[off]; break;
+            case 4: code = ((const uint32_t *)codes)[off]; break;
+            default: code = ((const uint64_t *)codes)[off]; break;
+            }
+            if (code >= (uint64_t)K) return 2;
+            s = s + tables[m * K + (int64_t)code];
+        }
+        out[i] = s;
+    }
+    return 0;
+}
+
+int pqo_abi_version(void) { return 4; }

@@ -63,6 +63,10 @@ def lib():
         L.pqo_at_dot_b.argtypes = [_fp, _i64, _i64, _i64, _fp, _i64, _i64, _fp, ctypes.c_int]
         L.pqo_opq_train_step.restype = ctypes.c_int
         L.pqo_opq_train_step.argtypes = [_fp, _i64, _i64, _i64, _fp, _fp, _i64, _i64, _i64, _fp, ctypes.c_int]
+        L.pqo_adc_tables.restype = ctypes.c_int
+        L.pqo_adc_tables.argtypes = [_fp, _i64, _i64, _i64, _fp, _fp, _fp]
+        L.pqo_adc_scan.restype = ctypes.c_int
+        L.pqo_adc_scan.argtypes = [_fp, _i64, _i64, _vp, ctypes.c_int, _i64, _i64, _i64, _fp]
         _lib = L
     return _lib
 
@@ -224,3 +228,41 @@ def opq_train_step(quantizers, projection, x, n_threads=1):
     rc = lib().pqo_opq_train_step(_p(q), M, K, dsub, _p(P), _p(x), x.shape[0], rs, cs, _p(cross), n_threads)
     assert rc == 0, rc
     return q, cross
+
+
+# ---- "next" row rank 4: asymmetric distance computation over codes -------------------------------
+def adc_tables(quantizers, query, projection=None):
+    """tables [M, K]: tables[m, j] = squared distance of the query's m-th sub-vector to centroid j,
+    evaluated as `instance.squared_euclidean_distance(centroids)` (linalg.rs:118-148); the query is
+    rotated first (pq.rs:293) when a projection is given.  A [nq, d] query matrix gives [nq, M, K]."""
+    q = _f32c(quantizers)
+    M, K, dsub = q.shape
+    y = _f32c(query)
+    P = _f32c(projection) if projection is not None else None
+    single = y.ndim == 1
+    y2 = y[None] if single else y
+    assert y2.shape[1] == M * dsub, "Quantizer and vector length mismatch"
+    out = np.empty((y2.shape[0], M, K), np.float32)
+    for i in range(y2.shape[0]):
+        yi = np.ascontiguousarray(y2[i])
+        lib().pqo_adc_tables(_p(q), M, K, dsub, _p(P), _p(yi), _p(out[i]))
+    return out[0] if single else out
+
+
+def adc_scan(tables, codes):
+    """dist[i] = sum_m tables[m, codes[i, m]] (sequential f32 sum over m from +0); tables [M, K] -> [n],
+    tables [nq, M, K] -> [nq, n]."""
+    t = _f32c(tables)
+    single = t.ndim == 2
+    t3 = t[None] if single else t
+    codes = np.asarray(codes)
+    assert codes.ndim == 2 and codes.shape[1] == t3.shape[1]
+    crs, ccs = _estrides(codes) if codes.size else (codes.shape[1], 1)
+    out = np.empty((t3.shape[0], codes.shape[0]), np.float32)
+    for i in range(t3.shape[0]):
+        rc = lib().pqo_adc_scan(_p(np.ascontiguousarray(t3[i])), t3.shape[1], t3.shape[2], codes.ctypes.data_as(_vp),
+                                codes.itemsize, codes.shape[0], crs, ccs, _p(out[i]))
+        if rc == 2:
+            raise IndexError("code >= K")
+        assert rc == 0, rc
+    return out[0] if single else out

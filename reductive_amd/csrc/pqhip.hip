@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -24,6 +25,7 @@
 #include "kernels_mfma.hip.h"
 #include "kernels_rotate.hip.h"
 #include "kernels_kmeans.hip.h"
+#include "kernels_adc.hip.h"
 #include "encode_launch.h"
 
 using namespace pqhip;
@@ -49,7 +51,31 @@ thread_local std::string g_hip_err;
     } while (0)
 
 constexpr int64_t kStageRows = 1 << 16;      // rows per staging buffer (host-resident calls)
-constexpr int64_t kScratchBytesMax = 16ll << 30;  // OPQ scratch per device: up to 16 GB of the 288 GB HBM
+constexpr int64_t kScratchBytesMax = 2ll << 30;   // one leased scratch buffer: <= 2 GiB (larger batches are chunked)
+constexpr int kScratchPoolMax = 4;                // leased scratch buffers per (codebook, device): <= 8 GiB of the 288 GB HBM
+constexpr int kErrSlots = 64;                     // per-stream "code >= K" flags per (codebook, device)
+constexpr int kTrainWs = 10;                      // grow-only training workspaces per device
+
+// RAII: every entry point runs on the device it was asked for and leaves the caller's thread on the
+// device it came with (torch callers in the same process keep their current device).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int ordinal)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        err = hipSetDevice(ordinal);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define SET_DEVICE(ordinal)        \
+    DeviceGuard dev_guard__(ordinal); \
+    HIPCHK(dev_guard__.err)
 
 struct Staging {
     void* h_in = nullptr;   // pinned
@@ -67,8 +93,20 @@ struct DeviceSlot {
     // grow-only device workspaces of the training entry points (a 12 GB hipMalloc + hipFree per
     // call costs ~0.4 s); used under `train_mu`, released with the context
     std::mutex train_mu;
-    void* ws[3] = {nullptr, nullptr, nullptr};
-    size_t ws_bytes[3] = {0, 0, 0};
+    void* ws[kTrainWs] = {};
+    size_t ws_bytes[kTrainWs] = {};
+};
+
+// One leasable scratch buffer (rotated rows of the OPQ paths, partial-minimum keys of K > 256).
+// A buffer is handed to exactly one call at a time (`leased`, under the codebook mutex); `done` is
+// recorded on the call's stream when its last launch has been enqueued, and the next lessee's stream
+// waits for it.  A buffer is only ever freed while it is not leased AND its event has completed, so
+// no caller can launch on (or be about to launch on) freed memory.
+struct ScratchBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+    bool leased = false;
 };
 
 struct CodebookDev {
@@ -77,12 +115,10 @@ struct CodebookDev {
     float* cc = nullptr;     // [M][k_pad]
     float* P = nullptr;      // [d][d]   x.dot(P)
     float* PT = nullptr;     // [d][d]   r.dot(P^T)
-    int* err = nullptr;      // bit 0: code >= K seen by reconstruct
-    unsigned long long* keys = nullptr;  // grouped codebooks (K > 256): [rows][M * groups] partial minima
-    int64_t keys_rows = 0;
-    float* scratch = nullptr;
-    int64_t scratch_rows = 0;
-    hipEvent_t scratch_done = nullptr;
+    int* err = nullptr;      // [0] unused, [1] "some ||c||^2 not finite" (k_check_norms), [2 .. 2 + kErrSlots):
+                             // "code >= K / row index out of range seen by reconstruct", one flag per caller stream
+    std::vector<hipStream_t> err_streams;  // stream of flag slot i (under cb->mu); more streams than slots share the last
+    std::vector<ScratchBuf> pool;          // under cb->mu
 };
 
 }  // namespace
@@ -109,7 +145,8 @@ struct pqhip_codebook {
     int variant = 0;        // 0 auto, 1 anchor, 2 mfma
     std::vector<CodebookDev> dev;
     std::atomic<const char*> last_kernel{""};
-    std::mutex mu;  // guards scratch (re)allocation
+    std::mutex mu;  // guards the scratch pools and the stream -> flag-slot tables
+    std::condition_variable cv;  // a scratch buffer was released
 };
 
 namespace {
@@ -148,30 +185,108 @@ void free_staging(Staging& s)
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Lease a scratch buffer of at least `bytes` for one call on stream `st` (see ScratchBuf).  Preference:
+// an idle buffer that is large enough; an idle buffer that has to grow (or a new one while the pool is
+// below kScratchPoolMax); otherwise the call queues behind a buffer whose work is still in flight
+// (stream order through its event) or, when every buffer is leased to another host thread, waits for a
+// release.  On return the buffer is exclusively this call's until release_scratch().
+int32_t lease_scratch(pqhip_codebook* cb, int slot, size_t bytes, hipStream_t st, int* out_idx)
+{
+    CodebookDev& cd = cb->dev[slot];
+    std::unique_lock<std::mutex> lk(cb->mu);
+    for (;;) {
+        int idle_fit = -1, idle_any = -1, busy_fit = -1, busy_any = -1;
+        for (int i = 0; i < (int)cd.pool.size(); ++i) {
+            ScratchBuf& b = cd.pool[i];
+            if (b.leased) continue;
+            const bool idle = hipEventQuery(b.done) == hipSuccess;
+            (void)hipGetLastError();
+            const bool fit = b.bytes >= bytes;
+            if (idle && fit && idle_fit < 0) idle_fit = i;
+            if (idle && idle_any < 0) idle_any = i;
+            if (!idle && fit && busy_fit < 0) busy_fit = i;
+            if (!idle && busy_any < 0) busy_any = i;
+        }
+        int pick = idle_fit;
+        if (pick < 0 && (int)cd.pool.size() < kScratchPoolMax) {
+            ScratchBuf nb;
+            HIPCHK(hipEventCreateWithFlags(&nb.done, hipEventDisableTiming));
+            cd.pool.push_back(nb);   // empty: grown below (a never-recorded event counts as complete)
+            pick = (int)cd.pool.size() - 1;
+        }
+        if (pick < 0) pick = idle_any >= 0 ? idle_any : busy_fit >= 0 ? busy_fit : busy_any;
+        if (pick < 0) {              // every buffer is leased to another host thread
+            cb->cv.wait(lk);
+            continue;
+        }
+        ScratchBuf& b = cd.pool[pick];
+        if (b.bytes < bytes) {
+            // not leased, so no host thread holds this pointer; wait for the device work that still
+            // uses it, then replace it
+            HIPCHK(hipEventSynchronize(b.done));
+            if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+            HIPCHK(hipMalloc(&b.p, bytes));
+            b.bytes = bytes;
+        }
+        b.leased = true;
+        HIPCHK(hipStreamWaitEvent(st, b.done, 0));
+        *out_idx = pick;
+        return PQHIP_OK;
+    }
+}
+
+void release_scratch(pqhip_codebook* cb, int slot, int idx, hipStream_t st)
+{
+    CodebookDev& cd = cb->dev[slot];
+    {
+        std::lock_guard<std::mutex> g(cb->mu);
+        (void)hipEventRecord(cd.pool[idx].done, st);
+        cd.pool[idx].leased = false;
+    }
+    cb->cv.notify_one();
+}
+
+struct ScratchLease {
+    pqhip_codebook* cb;
+    int slot, idx = -1;
+    hipStream_t st;
+    ScratchLease(pqhip_codebook* c, int s, hipStream_t t) : cb(c), slot(s), st(t) {}
+    ~ScratchLease() { if (idx >= 0) release_scratch(cb, slot, idx, st); }
+    int32_t acquire(size_t bytes) { return lease_scratch(cb, slot, bytes, st, &idx); }
+    void* ptr() const { return cb->dev[slot].pool[idx].p; }  // stable while leased (vector elements are never erased; growth happens under cb->mu before the pointer is read)
+};
+
+// device flag of "code >= K / row index out of range" for calls on stream `st`
+int* err_flag_for(pqhip_codebook* cb, int slot, hipStream_t st)
+{
+    CodebookDev& cd = cb->dev[slot];
+    std::lock_guard<std::mutex> g(cb->mu);
+    int i = 0;
+    for (; i < (int)cd.err_streams.size(); ++i)
+        if (cd.err_streams[i] == st) break;
+    if (i == (int)cd.err_streams.size()) {
+        if (i < kErrSlots) cd.err_streams.push_back(st);
+        else i = kErrSlots - 1;
+    }
+    return cd.err + 2 + i;
+}
+
 // K > 256 on the MFMA path: every subquantizer is presented to the default kernel as `groups`
 // virtual subquantizers of 256 centroids; the kernel leaves a 64-bit key {ordered distance, global
 // index} per (row, virtual m) and k_merge_keys reduces them to u32 codes.  Rows are chunked so that
-// the key buffer stays <= 1 GiB; the buffer is shared by all streams using this codebook on the
-// device, ordered through the same event as the OPQ scratch.
+// the key buffer stays <= 1 GiB; the buffer is leased from the codebook's scratch pool for the call.
 int32_t encode_grouped_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
                            void* d_codes, int64_t o_rs, hipStream_t st)
 {
     CodebookDev& cd = cb->dev[slot];
     const int64_t Mv = cb->M * cb->groups;
     const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(4096, (1ll << 30) / (Mv * 8)));
-    if (cd.keys_rows < chunk) {
-        std::lock_guard<std::mutex> g(cb->mu);
-        if (cd.keys_rows < chunk) {
-            if (cd.keys) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(cd.keys); cd.keys = nullptr; cd.keys_rows = 0; }
-            HIPCHK(hipMalloc((void**)&cd.keys, (size_t)chunk * Mv * sizeof(unsigned long long)));
-            cd.keys_rows = chunk;
-        }
-    }
-    HIPCHK(hipStreamWaitEvent(st, cd.scratch_done, 0));
+    ScratchLease keys(cb, slot, st);
+    PQCHK(keys.acquire((size_t)chunk * Mv * sizeof(unsigned long long)));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t rows = std::min<int64_t>(chunk, n - r0);
         EncodeArgs a;
-        a.x = d_x + r0 * x_rs; a.n = rows; a.x_rs = x_rs; a.out = cd.keys; a.o_rs = Mv;
+        a.x = d_x + r0 * x_rs; a.n = rows; a.x_rs = x_rs; a.out = keys.ptr(); a.o_rs = Mv;
         a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
         a.M = (int)Mv; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
         a.groups = cb->groups;
@@ -184,11 +299,10 @@ int32_t encode_grouped_dev(pqhip_codebook* cb, int slot, const float* d_x, int64
         const dim3 grid((unsigned)(a.chunks_per_xcd * Mv * 8));
         if (!launch_encode_mfma(2, 8, cb->DP, cb->DP == cb->dsub, 8, a, grid, st)) return PQHIP_EUNSUPPORTED;
         const unsigned mg = (unsigned)std::min<int64_t>((rows * cb->M + 255) / 256, 256 * 32);
-        hipLaunchKernelGGL((k_merge_keys<uint32_t>), dim3(mg), dim3(256), 0, st, cd.keys, rows, (int)cb->M, cb->groups,
+        hipLaunchKernelGGL((k_merge_keys<uint32_t>), dim3(mg), dim3(256), 0, st, (const unsigned long long*)keys.ptr(), rows, (int)cb->M, cb->groups,
                            (uint32_t*)d_codes + r0 * o_rs, o_rs);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(cd.scratch_done, st));
     cb->last_kernel = "k_encode_mfma_lds3<grouped>";
     return PQHIP_OK;
 }
@@ -442,15 +556,14 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
     for (size_t i = 0; i < ctx->devs.size(); ++i) {
         if (only_slot >= 0 && (int)i != only_slot) continue;
         CodebookDev& cd = cb->dev[i];
-        HIPCHK(hipSetDevice(ctx->devs[i]->ordinal));
+        SET_DEVICE(ctx->devs[i]->ordinal);
         hipStream_t st = ctx->devs[i]->stream[0];
         const size_t cb_bytes = (size_t)(M * K * dsub) * sizeof(float);
         HIPCHK(hipMalloc((void**)&cd.cb, cb_bytes));
         HIPCHK(hipMemcpyAsync(cd.cb, quantizers, cb_bytes, hipMemcpyHostToDevice, st));
         HIPCHK(hipMalloc((void**)&cd.cc, (size_t)M * cb->k_pad * sizeof(float)));
-        HIPCHK(hipMalloc((void**)&cd.err, 2 * sizeof(int)));
-        HIPCHK(hipMemsetAsync(cd.err, 0, 2 * sizeof(int), st));
-        HIPCHK(hipEventCreateWithFlags(&cd.scratch_done, hipEventDisableTiming));
+        HIPCHK(hipMalloc((void**)&cd.err, (2 + kErrSlots) * sizeof(int)));
+        HIPCHK(hipMemsetAsync(cd.err, 0, (2 + kErrSlots) * sizeof(int), st));
         if (T) HIPCHK(hipMalloc((void**)&cd.frags, (size_t)(M * groups * T * S * 64) * sizeof(float)));
         if (projection) {
             const size_t pb = (size_t)cb->d * cb->d * sizeof(float);
@@ -461,8 +574,7 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
         }
         bool ok = true;
         PQCHK(prepare_codebook_dev(cb, (int)i, st, &ok));
-        if (!ok) norms_ok = false;
-        HIPCHK(hipEventRecord(cd.scratch_done, st));
+        if (!ok) norms_ok = false;   // (prepare_codebook_dev returns synchronised: the device copy is ready for any stream)
     }
     cb->norms_ok = norms_ok;
     *out = cb;
@@ -479,6 +591,15 @@ struct DevBuf {
         return PQHIP_OK;
     }
 };
+
+int32_t ensure_ws(DeviceSlot& ds, int i, size_t bytes)
+{
+    if (ds.ws_bytes[i] >= bytes) return PQHIP_OK;
+    if (ds.ws[i]) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(ds.ws[i]); ds.ws[i] = nullptr; ds.ws_bytes[i] = 0; }
+    HIPCHK(hipMalloc(&ds.ws[i], bytes));
+    ds.ws_bytes[i] = bytes;
+    return PQHIP_OK;
+}
 
 // `n_iterations` x kmeans_iteration (kmeans.rs:308-327) on every subquantizer of `cb`, whose
 // device copy on `slot` is updated in place.  Work on one stream; returns synchronised.
@@ -508,14 +629,21 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
     const int64_t rpb = std::max<int64_t>(4096, round_up((wrows + 255) / 256, 64));
     const int nb_max = (int)((wrows + rpb - 1) / rpb);
     const int64_t w_pad = round_up(wrows, 4);  // 16-byte aligned row-id groups for every subquantizer
-    DevBuf codes, counts, seg, perm, loss, acc, tot;
-    PQCHK(codes.alloc((size_t)n * M * code_bytes));
-    PQCHK(counts.alloc((size_t)M * nb_max * K * sizeof(unsigned)));
-    PQCHK(seg.alloc((size_t)M * (K + 1) * sizeof(unsigned)));
-    PQCHK(perm.alloc((size_t)M * w_pad * sizeof(unsigned)));
-    PQCHK(loss.alloc((size_t)M * sizeof(float)));
-    PQCHK(acc.alloc((size_t)(M * K * dsub) * sizeof(float)));
-    PQCHK(tot.alloc((size_t)2 * M * K * sizeof(unsigned)));
+    // work buffers: the device's grow-only training workspaces 3..9 (the caller holds ds.train_mu);
+    // seven hipMalloc/hipFree per call used to cost more than a small training set's iterations
+    DeviceSlot& ds = *cb->ctx->devs[slot];
+    struct { void* p = nullptr; } codes, counts, seg, perm, loss, acc, tot;
+    {
+        const size_t need[7] = {(size_t)n * M * code_bytes, (size_t)M * nb_max * K * sizeof(unsigned),
+                                (size_t)M * (K + 1) * sizeof(unsigned), (size_t)M * w_pad * sizeof(unsigned),
+                                (size_t)M * sizeof(float), (size_t)(M * K * dsub) * sizeof(float),
+                                (size_t)2 * M * K * sizeof(unsigned)};
+        void** dst[7] = {&codes.p, &counts.p, &seg.p, &perm.p, &loss.p, &acc.p, &tot.p};
+        for (int i = 0; i < 7; ++i) {
+            PQCHK(ensure_ws(ds, 3 + i, std::max<size_t>(need[i], 16)));
+            *dst[i] = ds.ws[3 + i];
+        }
+    }
     const size_t lds_k = (size_t)K * sizeof(unsigned), lds_scan = (size_t)(K + 256) * sizeof(unsigned);
     HIPCHK(hipFuncSetAttribute((const void*)k_km_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     const float len_f = (float)(uint64_t)(n * dsub);  // `instances.len().as_()` (kmeans.rs:359)
@@ -671,15 +799,6 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
     return PQHIP_OK;
 }
 
-int32_t ensure_ws(DeviceSlot& ds, int i, size_t bytes)
-{
-    if (ds.ws_bytes[i] >= bytes) return PQHIP_OK;
-    if (ds.ws[i]) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(ds.ws[i]); ds.ws[i] = nullptr; ds.ws_bytes[i] = 0; }
-    HIPCHK(hipMalloc(&ds.ws[i], bytes));
-    ds.ws_bytes[i] = bytes;
-    return PQHIP_OK;
-}
-
 // C[da][db] (device, row stride pb floats, padded to multiples of 64) = A^T . B over n rows with
 // rule-2 arithmetic (k_atb_blocks / k_atb_fold).  Row blocks are processed in groups whose partial
 // matrices fit 256 MiB; the fold carries C from group to group, so the block order is the row order.
@@ -709,25 +828,8 @@ int32_t atb_dev(DeviceSlot& ds, const float* dA, int64_t a_rs, int da, const flo
     return PQHIP_OK;
 }
 
-int32_t ensure_scratch(pqhip_codebook* cb, int slot, int64_t rows)
-{
-    CodebookDev& cd = cb->dev[slot];
-    if (cd.scratch_rows >= rows) return PQHIP_OK;
-    std::lock_guard<std::mutex> g(cb->mu);
-    if (cd.scratch_rows >= rows) return PQHIP_OK;
-    if (cd.scratch) {
-        HIPCHK(hipDeviceSynchronize());
-        (void)hipFree(cd.scratch);
-        cd.scratch = nullptr;
-        cd.scratch_rows = 0;
-    }
-    HIPCHK(hipMalloc((void**)&cd.scratch, (size_t)rows * cb->d * sizeof(float)));
-    cd.scratch_rows = rows;
-    return PQHIP_OK;
-}
-
 int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes, int64_t n,
-                   int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st,
+                   int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st, int* err,
                    const int64_t* sel_rows = nullptr, int64_t n_codes = 0, const float* sel_scales = nullptr)
 {
     if (n == 0) return PQHIP_OK;
@@ -751,10 +853,10 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
         const unsigned g = (unsigned)std::min<int64_t>((n * d + 255) / 256, 256 * 32);
         if (code_bytes == 1)
             hipLaunchKernelGGL((k_reconstruct_any<uint8_t>), dim3(g), dim3(256), 0, st, (const uint8_t*)d_codes, n, c_rs,
-                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, cd.err, sel_rows, n_codes, sel_scales);
+                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, err, sel_rows, n_codes, sel_scales);
         else if (code_bytes == 4)
             hipLaunchKernelGGL((k_reconstruct_any<uint32_t>), dim3(g), dim3(256), 0, st, (const uint32_t*)d_codes, n, c_rs,
-                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, cd.err, sel_rows, n_codes, sel_scales);
+                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, err, sel_rows, n_codes, sel_scales);
         else
             return PQHIP_EUNSUPPORTED;
         HIPCHK(hipGetLastError());
@@ -771,12 +873,12 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
         if (sel_rows)                                                                             \
             hipLaunchKernelGGL((k_reconstruct<IDX, V, true, GG>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
-                               (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, cd.err,        \
+                               (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
                                sel_rows, n_codes, sel_scales);                                    \
         else                                                                                      \
             hipLaunchKernelGGL((k_reconstruct<IDX, V, false, GG>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
-                               (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, cd.err,        \
+                               (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
                                (const int64_t*)nullptr, (int64_t)0, (const float*)nullptr);       \
     } while (0)
 #define LAUNCH_REC(IDX)                                                                           \
@@ -799,18 +901,18 @@ int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_
                           void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st)
 {
     if (!cb->has_proj) return encode_plain_dev(cb, slot, d_x, n, x_rs, d_codes, code_bytes, o_rs, st);
-    // OPQ (pq.rs:276): rx = x.dot(P) into scratch, chunked, then PQ encode of rx
-    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
-    PQCHK(ensure_scratch(cb, slot, chunk));
+    // OPQ (pq.rs:276): rx = x.dot(P) into a leased scratch buffer, chunked, then PQ encode of rx
+    if (n == 0) return PQHIP_OK;
     CodebookDev& cd = cb->dev[slot];
-    HIPCHK(hipStreamWaitEvent(st, cd.scratch_done, 0));
+    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
+    ScratchLease rx(cb, slot, st);
+    PQCHK(rx.acquire((size_t)chunk * cb->d * sizeof(float)));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t rows = std::min<int64_t>(chunk, n - r0);
-        PQCHK(rotate_dev(d_x + r0 * x_rs, rows, x_rs, cd.P, (int)cb->d, cd.scratch, cb->d, st));
-        PQCHK(encode_plain_dev(cb, slot, cd.scratch, rows, cb->d,
+        PQCHK(rotate_dev(d_x + r0 * x_rs, rows, x_rs, cd.P, (int)cb->d, (float*)rx.ptr(), cb->d, st));
+        PQCHK(encode_plain_dev(cb, slot, (const float*)rx.ptr(), rows, cb->d,
                                (char*)d_codes + r0 * o_rs * code_bytes, code_bytes, o_rs, st));
     }
-    HIPCHK(hipEventRecord(cd.scratch_done, st));
     return PQHIP_OK;
 }
 
@@ -821,21 +923,23 @@ int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, 
                              const int64_t* sel_rows = nullptr, int64_t n_codes = 0,
                              const float* sel_scales = nullptr)
 {
+    if (n == 0) return PQHIP_OK;
+    int* err = err_flag_for(cb, slot, st);
     if (!cb->has_proj)
-        return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st, sel_rows, n_codes, sel_scales);
-    // OPQ (pq.rs:323-326): gather into scratch, then out = r.dot(P^T); a lookup's scale comes last
-    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
-    PQCHK(ensure_scratch(cb, slot, chunk));
+        return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st, err, sel_rows, n_codes, sel_scales);
+    // OPQ (pq.rs:323-326): gather into a leased scratch buffer, then out = r.dot(P^T); a lookup's scale comes last
     CodebookDev& cd = cb->dev[slot];
-    HIPCHK(hipStreamWaitEvent(st, cd.scratch_done, 0));
+    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
+    ScratchLease rec(cb, slot, st);
+    PQCHK(rec.acquire((size_t)chunk * cb->d * sizeof(float)));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t rows = std::min<int64_t>(chunk, n - r0);
         if (sel_rows)
-            PQCHK(gather_dev(cb, slot, d_codes, code_bytes, rows, c_rs, cd.scratch, cb->d, st, sel_rows + r0, n_codes, nullptr));
+            PQCHK(gather_dev(cb, slot, d_codes, code_bytes, rows, c_rs, (float*)rec.ptr(), cb->d, st, err, sel_rows + r0, n_codes, nullptr));
         else
             PQCHK(gather_dev(cb, slot, (const char*)d_codes + r0 * c_rs * code_bytes, code_bytes, rows,
-                             c_rs, cd.scratch, cb->d, st));
-        PQCHK(rotate_dev(cd.scratch, rows, cb->d, cd.PT, (int)cb->d, d_out + r0 * o_rs, o_rs, st));
+                             c_rs, (float*)rec.ptr(), cb->d, st, err));
+        PQCHK(rotate_dev((const float*)rec.ptr(), rows, cb->d, cd.PT, (int)cb->d, d_out + r0 * o_rs, o_rs, st));
         if (sel_rows && sel_scales) {
             const unsigned g = (unsigned)std::min<int64_t>((rows * cb->d + 255) / 256, 256 * 32);
             hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, st, d_out + r0 * o_rs, rows, (int)cb->d, o_rs,
@@ -843,7 +947,6 @@ int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, 
             HIPCHK(hipGetLastError());
         }
     }
-    HIPCHK(hipEventRecord(cd.scratch_done, st));
     return PQHIP_OK;
 }
 
@@ -907,6 +1010,20 @@ uint64_t load_code(const void* base, int bytes, int64_t off)
     case 2: return ((const uint16_t*)base)[off];
     case 4: return ((const uint32_t*)base)[off];
     default: return ((const uint64_t*)base)[off];
+    }
+}
+
+template <int NV>
+int32_t launch_adc_nv(int nv, const uint8_t* codes, int64_t n, int64_t c_rs, const float* lut, int M, int K, float* out,
+                      int64_t rows_per_wg, unsigned grid, size_t lds, int* err, hipStream_t st)
+{
+    if constexpr (NV > kAdcMaxValueWords) {
+        return PQHIP_EUNSUPPORTED;
+    } else {
+        if (nv != NV) return launch_adc_nv<NV + 1>(nv, codes, n, c_rs, lut, M, K, out, rows_per_wg, grid, lds, err, st);
+        HIPCHK(hipFuncSetAttribute((const void*)k_adc_scan_u8<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((k_adc_scan_u8<NV>), dim3(grid), dim3(256), lds, st, codes, n, c_rs, lut, M, K, out, rows_per_wg, err);
+        return PQHIP_OK;
     }
 }
 
@@ -976,7 +1093,7 @@ int32_t pqhip_ctx_create(const int32_t* devices, int32_t n_devices, pqhip_ctx** 
         }
         std::unique_ptr<DeviceSlot> ds(new DeviceSlot());
         ds->ordinal = o;
-        HIPCHK(hipSetDevice(o));
+        SET_DEVICE(o);
         HIPCHK(hipStreamCreateWithFlags(&ds->stream[0], hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&ds->stream[1], hipStreamNonBlocking));
         ctx->devs.push_back(std::move(ds));
@@ -989,12 +1106,12 @@ void pqhip_ctx_destroy(pqhip_ctx* ctx)
 {
     if (!ctx) return;
     for (auto& ds : ctx->devs) {
-        (void)hipSetDevice(ds->ordinal);
+        DeviceGuard dg(ds->ordinal);
         for (int i = 0; i < 2; ++i) {
             if (ds->stream[i]) { (void)hipStreamSynchronize(ds->stream[i]); (void)hipStreamDestroy(ds->stream[i]); }
             free_staging(ds->st[i]);
         }
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < kTrainWs; ++i)
             if (ds->ws[i]) (void)hipFree(ds->ws[i]);
     }
     delete ctx;
@@ -1013,7 +1130,8 @@ void pqhip_codebook_destroy(pqhip_codebook* cb)
     if (!cb) return;
     for (size_t i = 0; i < cb->dev.size(); ++i) {
         CodebookDev& cd = cb->dev[i];
-        (void)hipSetDevice(cb->ctx->devs[i]->ordinal);
+        if (!cd.cb && !cd.err) continue;   // never built on this device (single-slot training handles)
+        DeviceGuard dg(cb->ctx->devs[i]->ordinal);
         (void)hipDeviceSynchronize();
         if (cd.cb) (void)hipFree(cd.cb);
         if (cd.frags) (void)hipFree(cd.frags);
@@ -1021,9 +1139,10 @@ void pqhip_codebook_destroy(pqhip_codebook* cb)
         if (cd.P) (void)hipFree(cd.P);
         if (cd.PT) (void)hipFree(cd.PT);
         if (cd.err) (void)hipFree(cd.err);
-        if (cd.scratch) (void)hipFree(cd.scratch);
-        if (cd.keys) (void)hipFree(cd.keys);
-        if (cd.scratch_done) (void)hipEventDestroy(cd.scratch_done);
+        for (ScratchBuf& b : cd.pool) {
+            if (b.p) (void)hipFree(b.p);
+            if (b.done) (void)hipEventDestroy(b.done);
+        }
     }
     delete cb;
 }
@@ -1056,7 +1175,7 @@ int32_t pqhip_quantize_batch_f32_dev(pqhip_codebook* cb, int32_t slot, const flo
     if (code_bytes != 1 && code_bytes != 4) return PQHIP_EUNSUPPORTED;
     if (code_bytes == 1 && cb->K > 256) return PQHIP_EINDEX_WIDTH;  // primitives.rs:31-34
     if (n > 0 && (x_rs < cb->d || o_rs < cb->M)) return PQHIP_ESHAPE;
-    HIPCHK(hipSetDevice(cb->ctx->devs[slot]->ordinal));
+    SET_DEVICE(cb->ctx->devs[slot]->ordinal);
     return quantize_dev_impl(cb, slot, d_x, n, x_rs, d_codes, code_bytes, o_rs, (hipStream_t)stream);
 }
 
@@ -1069,7 +1188,7 @@ int32_t pqhip_reconstruct_batch_f32_dev(pqhip_codebook* cb, int32_t slot, const 
     if (n > 0 && (!d_codes || !d_out)) return PQHIP_EINVAL;
     if (code_bytes != 1 && code_bytes != 4) return PQHIP_EUNSUPPORTED;
     if (n > 0 && (c_rs < cb->M || o_rs < cb->d)) return PQHIP_ESHAPE;
-    HIPCHK(hipSetDevice(cb->ctx->devs[slot]->ordinal));
+    SET_DEVICE(cb->ctx->devs[slot]->ordinal);
     return reconstruct_dev_impl(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs,
                                 (hipStream_t)stream);
 }
@@ -1086,20 +1205,92 @@ int32_t pqhip_reconstruct_rows_f32_dev(pqhip_codebook* cb, int32_t slot, const v
     if (n > 0 && (c_rs < cb->M || o_rs < cb->d)) return PQHIP_ESHAPE;
     if (n == 0) return PQHIP_OK;
     if (n_codes == 0) return PQHIP_ECODE_RANGE;  // every index is out of bounds
-    HIPCHK(hipSetDevice(cb->ctx->devs[slot]->ordinal));
+    SET_DEVICE(cb->ctx->devs[slot]->ordinal);
     return reconstruct_dev_impl(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, (hipStream_t)stream,
                                 d_rows, n_codes, d_scales);
+}
+
+// ---- "next" row: asymmetric distance computation over a resident code matrix ----------------------
+int32_t pqhip_adc_tables_f32_dev(pqhip_codebook* cb, int32_t slot, const float* d_q, int64_t nq, int64_t q_rs,
+                                 float* d_tables, void* stream)
+{
+    if (!cb || nq < 0) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
+    if (nq == 0) return PQHIP_OK;
+    if (!d_q || !d_tables) return PQHIP_EINVAL;
+    if (q_rs < cb->d) return PQHIP_ESHAPE;
+    if (nq > (1 << 20)) return PQHIP_EUNSUPPORTED;
+    SET_DEVICE(cb->ctx->devs[slot]->ordinal);
+    hipStream_t st = (hipStream_t)stream;
+    CodebookDev& cd = cb->dev[slot];
+    const float* y = d_q;
+    int64_t y_rs = q_rs;
+    ScratchLease rot(cb, slot, st);
+    if (cb->has_proj) {       // pq.rs:293: the query is rotated like a vector to be quantized
+        PQCHK(rot.acquire((size_t)nq * cb->d * sizeof(float)));
+        const int64_t total = nq * cb->d;
+        hipLaunchKernelGGL(k_adc_rotate_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_q, q_rs,
+                           (int)nq, cd.P, (int)cb->d, (float*)rot.ptr());
+        y = (const float*)rot.ptr();
+        y_rs = cb->d;
+    }
+    const int64_t total = nq * cb->M * cb->K;
+    hipLaunchKernelGGL(k_adc_tables, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, y_rs, (int)nq, cd.cb,
+                       cd.cc, (int)cb->M, (int)cb->K, (int)cb->dsub, cb->k_pad, d_tables);
+    HIPCHK(hipGetLastError());
+    return PQHIP_OK;
+}
+
+
+int32_t pqhip_adc_scan_f32_dev(pqhip_codebook* cb, int32_t slot, const float* d_tables, int64_t nq, const void* d_codes,
+                               int32_t code_bytes, int64_t n, int64_t c_rs, float* d_out, int64_t o_rs, void* stream)
+{
+    if (!cb || nq < 0 || n < 0) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
+    if (code_bytes != 1 && code_bytes != 4) return PQHIP_EUNSUPPORTED;
+    if (nq == 0 || n == 0) return PQHIP_OK;
+    if (!d_tables || !d_codes || !d_out) return PQHIP_EINVAL;
+    if (c_rs < cb->M || o_rs < n) return PQHIP_ESHAPE;
+    SET_DEVICE(cb->ctx->devs[slot]->ordinal);
+    hipStream_t st = (hipStream_t)stream;
+    int* err = err_flag_for(cb, slot, st);
+    const int M = (int)cb->M, K = (int)cb->K;
+    const size_t lds = (size_t)M * K * sizeof(float);
+    const int nv = (M + 3) / 4;
+    const bool fast = code_bytes == 1 && lds <= 160 * 1024 && nv <= kAdcMaxValueWords;
+    for (int64_t q = 0; q < nq; ++q) {
+        const float* lut = d_tables + q * (int64_t)M * K;
+        float* out = d_out + q * o_rs;
+        if (fast) {
+            // all workgroups resident at once, one contiguous row range each (the table is loaded once per workgroup)
+            const int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+            const int64_t max_wgs = (int64_t)256 * wgs_per_cu;
+            int64_t rows_per_wg = round_up((n + max_wgs - 1) / max_wgs, 256);
+            rows_per_wg = std::max<int64_t>(rows_per_wg, 1024);
+            const unsigned grid = (unsigned)((n + rows_per_wg - 1) / rows_per_wg);
+            PQCHK(launch_adc_nv<1>(nv, (const uint8_t*)d_codes, n, c_rs, lut, M, K, out, rows_per_wg, grid, lds, err, st));
+        } else {
+            const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 32);
+            if (code_bytes == 1)
+                hipLaunchKernelGGL((k_adc_scan_any<uint8_t>), dim3(grid), dim3(256), 0, st, (const uint8_t*)d_codes, n, c_rs, lut, M, K, out, err);
+            else
+                hipLaunchKernelGGL((k_adc_scan_any<uint32_t>), dim3(grid), dim3(256), 0, st, (const uint32_t*)d_codes, n, c_rs, lut, M, K, out, err);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return PQHIP_OK;
 }
 
 int32_t pqhip_check_codes_dev(pqhip_codebook* cb, int32_t slot, void* stream)
 {
     if (!cb) return PQHIP_EINVAL;
     if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
-    HIPCHK(hipSetDevice(cb->ctx->devs[slot]->ordinal));
+    SET_DEVICE(cb->ctx->devs[slot]->ordinal);
     hipStream_t st = (hipStream_t)stream;
+    int* d_flag = err_flag_for(cb, slot, st);   // the flag of THIS stream's calls: concurrent callers on other streams keep theirs
     int flag = 0;
-    HIPCHK(hipMemcpyAsync(&flag, cb->dev[slot].err, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemsetAsync(cb->dev[slot].err, 0, sizeof(int), st));
+    HIPCHK(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(d_flag, 0, sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));
     return flag ? PQHIP_ECODE_RANGE : PQHIP_OK;
 }
@@ -1122,7 +1313,7 @@ int32_t pqhip_quantize_batch_f32(pqhip_codebook* cb, const float* x, int64_t n, 
     return for_each_shard(cb->ctx, n, [&](int slot, int64_t rb, int64_t re) -> int32_t {
         DeviceSlot& ds = *cb->ctx->devs[slot];
         std::lock_guard<std::mutex> g(ds.mu);
-        HIPCHK(hipSetDevice(ds.ordinal));
+        SET_DEVICE(ds.ordinal);
         const int64_t cap = std::min<int64_t>(kStageRows, re - rb);
         for (int b = 0; b < 2; ++b)
             PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), (size_t)cap * d * sizeof(float)));
@@ -1181,7 +1372,7 @@ int32_t pqhip_reconstruct_batch_f32(pqhip_codebook* cb, const void* codes, int32
     return for_each_shard(cb->ctx, n, [&](int slot, int64_t rb, int64_t re) -> int32_t {
         DeviceSlot& ds = *cb->ctx->devs[slot];
         std::lock_guard<std::mutex> g(ds.mu);
-        HIPCHK(hipSetDevice(ds.ordinal));
+        SET_DEVICE(ds.ordinal);
         const int64_t cap = std::min<int64_t>(kStageRows, re - rb);
         for (int b = 0; b < 2; ++b)
             PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), (size_t)cap * d * sizeof(float)));
@@ -1247,11 +1438,12 @@ int32_t pqhip_kmeans_iterations_f32_dev(pqhip_ctx* ctx, int32_t slot, float* qua
     if (!ctx || !quantizers || n < 0 || n_iterations < 0) return PQHIP_EINVAL;
     if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
     if (n > 0 && (!d_x || x_rs < M * dsub)) return PQHIP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->devs[slot]->ordinal));
+    SET_DEVICE(ctx->devs[slot]->ordinal);
     pqhip_codebook* cb = nullptr;
     PQCHK(codebook_create_impl(ctx, quantizers, M, K, dsub, nullptr, slot, &cb));
     struct G { pqhip_codebook* p; ~G() { pqhip_codebook_destroy(p); } } g{cb};
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> tg(ctx->devs[slot]->train_mu);   // the device's training workspaces
     if (n_iterations > 0) PQCHK(kmeans_run_dev(cb, slot, d_x, n, x_rs, n_iterations, loss, st));
     HIPCHK(hipMemcpy(quantizers, cb->dev[slot].cb, (size_t)(M * K * dsub) * sizeof(float), hipMemcpyDeviceToHost));
     return PQHIP_OK;
@@ -1289,7 +1481,7 @@ int32_t pqhip_matrix_upload_f32(pqhip_ctx* ctx, int32_t slot, const float* x, in
     std::unique_ptr<pqhip_matrix> m(new pqhip_matrix());
     m->ctx = ctx; m->slot = slot; m->rows = n; m->cols = d;
     std::lock_guard<std::mutex> g(ds.mu);
-    HIPCHK(hipSetDevice(ds.ordinal));
+    SET_DEVICE(ds.ordinal);
     HIPCHK(hipMalloc((void**)&m->d, (size_t)std::max<int64_t>(n, 1) * d * sizeof(float)));
     struct Free { float* p; ~Free() { if (p) (void)hipFree(p); } } guard{m->d};
     const int64_t cap = std::min<int64_t>(kStageRows, std::max<int64_t>(n, 1));
@@ -1324,7 +1516,7 @@ int64_t pqhip_matrix_rows(const pqhip_matrix* m) { return m ? m->rows : 0; }
 void pqhip_matrix_destroy(pqhip_matrix* m)
 {
     if (!m) return;
-    (void)hipSetDevice(m->ctx->devs[m->slot]->ordinal);
+    DeviceGuard dg(m->ctx->devs[m->slot]->ordinal);
     if (m->d) (void)hipFree(m->d);
     delete m;
 }
@@ -1339,7 +1531,7 @@ int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx* ctx, int32_t slot, float* quanti
     if (M <= 0 || K <= 0 || dsub <= 0) return PQHIP_ESHAPE;
     const int64_t d = M * dsub;
     if (n > 0 && (!d_x || x_rs < d)) return PQHIP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->devs[slot]->ordinal));
+    SET_DEVICE(ctx->devs[slot]->ordinal);
     pqhip_codebook* cb = nullptr;
     PQCHK(codebook_create_impl(ctx, quantizers, M, K, dsub, projection, slot, &cb));
     struct G { pqhip_codebook* p; ~G() { pqhip_codebook_destroy(p); } } g{cb};
@@ -1360,7 +1552,7 @@ int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx* ctx, int32_t slot, float* quanti
     PQCHK(kmeans_run_dev(cb, slot, (const float*)rx.p, n, d, 1, nullptr, st));
     // opq.rs:176-182  quantize -> reconstruct round trip with the new centroids (rx is recycled)
     PQCHK(encode_plain_dev(cb, slot, (const float*)rx.p, n, d, codes.p, code_bytes, M, st));
-    PQCHK(gather_dev(cb, slot, codes.p, code_bytes, n, M, (float*)rx.p, d, st));
+    PQCHK(gather_dev(cb, slot, codes.p, code_bytes, n, M, (float*)rx.p, d, st, err_flag_for(cb, slot, st)));
     // opq.rs:191  instances.t().dot(&reconstructed)
     PQCHK(atb_dev(ds, d_x, x_rs, (int)d, (const float*)rx.p, d, (int)d, n, (float*)dcross.p, pa, pa, st));
     HIPCHK(hipMemcpy2DAsync(cross, (size_t)d * sizeof(float), dcross.p, (size_t)pa * sizeof(float),
@@ -1376,7 +1568,7 @@ int32_t pqhip_rotate_f32_dev(pqhip_ctx* ctx, int32_t slot, const float* d_x, int
     if (!ctx || !projection || n < 0 || d <= 0 || d > (1 << 24)) return PQHIP_EINVAL;
     if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
     if (n > 0 && (!d_x || !d_out || x_rs < d || o_rs < d)) return PQHIP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->devs[slot]->ordinal));
+    SET_DEVICE(ctx->devs[slot]->ordinal);
     hipStream_t st = (hipStream_t)stream;
     DevBuf dp;
     PQCHK(dp.alloc((size_t)d * d * sizeof(float)));
@@ -1392,7 +1584,7 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx* ctx, int32_t slot, const float* d_a, i
     if (!ctx || !out || n < 0 || da <= 0 || db <= 0 || da > 65536 || db > 65536) return PQHIP_EINVAL;
     if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
     if (n > 0 && (!d_a || !d_b || a_rs < da || b_rs < db)) return PQHIP_EINVAL;
-    HIPCHK(hipSetDevice(ctx->devs[slot]->ordinal));
+    SET_DEVICE(ctx->devs[slot]->ordinal);
     hipStream_t st = (hipStream_t)stream;
     const int pa = (int)round_up(da, 64), pb = (int)round_up(db, 64);
     DeviceSlot& ds = *ctx->devs[slot];
@@ -1412,7 +1604,7 @@ int32_t pqhip_selftest_mfma_chain(pqhip_ctx* ctx, int32_t slot, int32_t k, int32
     if (!ctx || !out_mismatches || k <= 0 || n_trials <= 0) return PQHIP_EINVAL;
     if (slot < 0 || slot >= (int)ctx->devs.size()) return PQHIP_ENODEV;
     DeviceSlot& ds = *ctx->devs[slot];
-    HIPCHK(hipSetDevice(ds.ordinal));
+    SET_DEVICE(ds.ordinal);
     unsigned long long* d_cnt = nullptr;
     HIPCHK(hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), ds.stream[0]));

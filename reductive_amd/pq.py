@@ -630,8 +630,11 @@ class Pq:
             raise _lib.PqHipError(rc, "pqhip_quantize_batch_f32_dev")
         return out
 
-    def reconstruct_batch_device(self, codes, out=None, stream=None, check=False):
-        """codes: CUDA uint8 tensor [n, M] -> float32 tensor [n, d]."""
+    def reconstruct_batch_device(self, codes, out=None, stream=None, check=True):
+        """codes: CUDA uint8 tensor [n, M] -> float32 tensor [n, d].
+        check=True (default) synchronises the stream and raises the reference's index panic
+        (primitives.rs:146) when a code >= K was met; check=False leaves the call asynchronous and the
+        violation pending on the stream's flag (a later check=True call on that stream reports it)."""
         import torch
         assert codes.is_cuda and codes.dtype == torch.uint8 and codes.dim() == 2
         if codes.shape[1] != self.quantized_len():
@@ -664,7 +667,7 @@ class Pq:
                 raise _lib.PqHipError(rc, "pqhip_check_codes_dev")
         return out
 
-    def reconstruct_rows_device(self, codes, rows, scales=None, out=None, stream=None, check=False):
+    def reconstruct_rows_device(self, codes, rows, scales=None, out=None, stream=None, check=True):
         """Lookup path of a resident quantized matrix ("next" row):
         `reconstruct_batch(codes.select(Axis(0), rows)) * scales.select(rows)` in one pass.
         codes: CUDA uint8 [N, M]; rows: CUDA int64 [n]; scales: None or CUDA float32 [N]."""
@@ -700,6 +703,68 @@ class Pq:
             raise PanicError("ndarray: index out of bounds")
         if rc != _lib.OK:
             raise _lib.PqHipError(rc, "pqhip_reconstruct_rows_f32_dev")
+        if check:
+            rc = _lib.lib().pqhip_check_codes_dev(cb, slot, ctypes.c_void_p(stream))
+            if rc == _lib.ECODE_RANGE:
+                raise PanicError("ndarray: index out of bounds")
+            if rc != _lib.OK:
+                raise _lib.PqHipError(rc, "pqhip_check_codes_dev")
+        return out
+
+    # ---- "next" row: asymmetric distance computation over resident codes -----
+    def adc_tables_device(self, queries, stream=None):
+        """queries: CUDA float32 [d] or [nq, d] -> tables [M, K] or [nq, M, K] with
+        tables[q, m, j] = `y_q[m].squared_euclidean_distance(quantizers[m])[j]` (linalg.rs:118-148;
+        y = query.dot(projection) first for OPQ, pq.rs:293)."""
+        import torch
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.dim() in (1, 2)
+        single = queries.dim() == 1
+        q2 = queries[None] if single else queries
+        if q2.shape[1] != self.reconstructed_len():
+            raise PanicError("Quantizer and vector length mismatch")
+        if q2.stride(1) != 1:
+            q2 = q2.contiguous()
+        M, K = self.quantized_len(), self.n_quantizer_centroids()
+        out = torch.empty((q2.shape[0], M, K), dtype=torch.float32, device=queries.device)
+        cb = self._cb()
+        if stream is None:
+            stream = torch.cuda.current_stream(queries.device).cuda_stream
+        rc = _lib.lib().pqhip_adc_tables_f32_dev(cb, self._slot_for(queries), q2.data_ptr(), q2.shape[0],
+                                                q2.stride(0) if q2.shape[0] > 1 else max(q2.stride(0), q2.shape[1]),
+                                                out.data_ptr(), ctypes.c_void_p(stream))
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_adc_tables_f32_dev")
+        return out[0] if single else out
+
+    def adc_scan_device(self, codes, tables, out=None, stream=None, check=False):
+        """codes: CUDA uint8 (or int32 when K > 256) [n, M]; tables: [M, K] or [nq, M, K] from
+        adc_tables_device -> distances [n] or [nq, n]: out[q, i] = sum_m tables[q, m, codes[i, m]]
+        (sequential f32 sum over m)."""
+        import torch
+        assert codes.is_cuda and codes.dtype in (torch.uint8, torch.int32) and codes.dim() == 2
+        assert tables.is_cuda and tables.dtype == torch.float32 and tables.is_contiguous()
+        M, K = self.quantized_len(), self.n_quantizer_centroids()
+        if codes.shape[1] != M:
+            raise PanicError("Quantization length does not match number of subquantizers")
+        single = tables.dim() == 2
+        if tuple(tables.shape[-2:]) != (M, K):
+            raise PanicError("lookup tables must be [.., %d, %d]" % (M, K))
+        nq = 1 if single else tables.shape[0]
+        if codes.stride(1) != 1:
+            codes = codes.contiguous()
+        n = codes.shape[0]
+        if out is None:
+            out = torch.empty((n,) if single else (nq, n), dtype=torch.float32, device=codes.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == nq * n
+        cb = self._cb()
+        if stream is None:
+            stream = torch.cuda.current_stream(codes.device).cuda_stream
+        slot = self._slot_for(codes)
+        rc = _lib.lib().pqhip_adc_scan_f32_dev(cb, slot, tables.data_ptr(), nq, codes.data_ptr(), codes.element_size(), n,
+                                              codes.stride(0) if n > 1 else max(codes.stride(0), M),
+                                              out.data_ptr(), n, ctypes.c_void_p(stream))
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_adc_scan_f32_dev")
         if check:
             rc = _lib.lib().pqhip_check_codes_dev(cb, slot, ctypes.c_void_p(stream))
             if rc == _lib.ECODE_RANGE:
