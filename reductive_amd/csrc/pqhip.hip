@@ -27,6 +27,7 @@
 #include "kernels_kmeans.hip.h"
 #include "kernels_adc.hip.h"
 #include "encode_launch.h"
+#include "opq_fused_launch.h"
 
 using namespace pqhip;
 
@@ -315,6 +316,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
                          const int* bad_flag = nullptr)
 {
     if (n == 0) return PQHIP_OK;
+    if (cb->variant == 5 && !cb->has_proj) return PQHIP_EUNSUPPORTED;   // variant 5 = fused OPQ kernel only
     CodebookDev& cd = cb->dev[slot];
     if (cb->groups > 1 && cb->variant != 1 && cb->norms_ok && code_bytes == 4)
         return encode_grouped_dev(cb, slot, d_x, n, x_rs, d_codes, o_rs, st);
@@ -901,9 +903,59 @@ int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_
                           void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st)
 {
     if (!cb->has_proj) return encode_plain_dev(cb, slot, d_x, n, x_rs, d_codes, code_bytes, o_rs, st);
-    // OPQ (pq.rs:276): rx = x.dot(P) into a leased scratch buffer, chunked, then PQ encode of rx
     if (n == 0) return PQHIP_OK;
     CodebookDev& cd = cb->dev[slot];
+    // OPQ (pq.rs:276) in one kernel, on request (encode variant 5, or PQHIP_FUSED_OPQ=1 for the auto variant):
+    // the rotated rows never leave the register file (kernels_opq_fused.hip.h), no scratch buffer.  Needs u8
+    // codes from a 97..256-centroid codebook with finite norms, an even sub-dimension <= 32 that has an
+    // instantiation, 16-byte aligned rows and a P block that fits LDS (d <= 316).  Measured 5 % slower than
+    // the two-kernel path below on the 10 M x 300 shape (numbers in the kernel's header), hence not the default.
+    {
+        const int DP = (int)cb->dsub;
+        static const bool env_fused = getenv("PQHIP_FUSED_OPQ") != nullptr;
+        const bool want_fused = cb->variant == 5 || (cb->variant == 0 && env_fused);
+        const bool vec = (cb->d % 4 == 0) && (x_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
+        if (want_fused && code_bytes == 1 && cb->groups == 1 && cb->T != 0 && cb->norms_ok && cb->dsub % 2 == 0 &&
+            cb->dsub <= 32 && opq_fused_has(DP, cb->T) && vec && opq_fused_lds_bytes(DP, (int)cb->d) <= 160 * 1024) {
+            OpqFusedArgs a;
+            a.x = d_x; a.n = n; a.x_rs = x_rs; a.P = cd.P; a.d = (int)cb->d;
+            a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
+            a.out = (uint8_t*)d_codes; a.o_rs = o_rs;
+            a.M = (int)cb->M; a.K = (int)cb->K; a.k_pad = cb->k_pad;
+            a.rows_per_wg = 8192;
+            const int nm = 64 / DP;
+            a.ncb = (int)((cb->M + nm - 1) / nm);
+            const int64_t n_rg = (n + a.rows_per_wg - 1) / a.rows_per_wg;
+            a.rg_per_xcd = (n_rg + 7) / 8;
+            const dim3 grid((unsigned)(a.rg_per_xcd * a.ncb * 8));
+            a.stamps = nullptr;
+            static const bool want_stamps = getenv("PQHIP_DEBUG_FUSED_STAMP") != nullptr;
+            DevBuf stamp_buf;
+            const size_t n_stamp = (size_t)grid.x * 8 * 5;
+            if (want_stamps) {
+                PQCHK(stamp_buf.alloc(n_stamp * sizeof(unsigned long long)));
+                HIPCHK(hipMemsetAsync(stamp_buf.p, 0, n_stamp * sizeof(unsigned long long), st));
+                a.stamps = (unsigned long long*)stamp_buf.p;
+            }
+            const int e = launch_opq_fused(DP, cb->T, a, grid, opq_fused_lds_bytes(DP, (int)cb->d), st);
+            if (e != 0) { g_hip_err = std::string("k_opq_encode_fused: ") + hipGetErrorString((hipError_t)e); return PQHIP_EHIP; }
+            if (want_stamps) {   // diagnostics: synchronous summary on stderr
+                std::vector<unsigned long long> h(n_stamp);
+                HIPCHK(hipMemcpyAsync(h.data(), stamp_buf.p, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                double tiles = 0, rot = 0, enc = 0, cyc = 0, rt = 0; size_t waves = 0;
+                for (size_t i = 0; i < n_stamp; i += 5)
+                    if (h[i]) { tiles += (double)h[i]; rot += (double)h[i + 1]; enc += (double)h[i + 2]; cyc += (double)h[i + 3]; rt += (double)h[i + 4]; ++waves; }
+                if (tiles > 0)
+                    fprintf(stderr, "[pqhip] fused stamps: %zu waves, %.1f tiles/wave, rotation %.0f cyc/tile, encode %.0f cyc/tile, wave life %.0f cyc, clock %.0f MHz\n",
+                            waves, tiles / waves, rot / tiles, enc / tiles, cyc / waves, rt > 0 ? cyc / rt * 100.0 : 0.0);
+            }
+            cb->last_kernel = "k_opq_encode_fused";
+            return PQHIP_OK;
+        }
+        if (cb->variant == 5) return PQHIP_EUNSUPPORTED;
+    }
+    // otherwise: rx = x.dot(P) into a leased scratch buffer, chunked, then PQ encode of rx
     const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
     ScratchLease rx(cb, slot, st);
     PQCHK(rx.acquire((size_t)chunk * cb->d * sizeof(float)));
@@ -1154,7 +1206,7 @@ int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && c
 
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {
-    if (!cb || variant < 0 || variant > 4) return PQHIP_EINVAL;
+    if (!cb || variant < 0 || variant > 5) return PQHIP_EINVAL;
     cb->variant = variant;
     return PQHIP_OK;
 }

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): for every bench workload whose dominant kernel carries a roofline
+# record, one `rocprofv3 --kernel-trace --stats` pass and two SEPARATE counter passes (FETCH_SIZE,
+# WRITE_SIZE; never combined with other trace domains), then tools/pmc_summarize.py turns them into
+# profiles/pmc_traffic.json entries stamped with the kernel-source hash bench.py checks.
+# usage: tools/pmc_collect.sh <tag> [workload ...]      (default: the four single-GPU BASELINE configs + lookup + adc_scan)
+set -u
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+WL=${*:-"encode opq_encode reconstruct reconstruct100 encode_d768 lookup adc_scan"}
+for W in $WL; do
+  case $W in
+    reconstruct100) ARGS="--workload reconstruct --rows 100000000";;
+    *) ARGS="--workload $W";;
+  esac
+  CMD="$R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-sub-configs"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/stats -- python3 $CMD > $OUT/$W.bench.json 2> $OUT/$W.stats.err || echo "stats pass failed: $W"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/$W/fetch -- python3 $CMD > /dev/null 2> $OUT/$W.fetch.err || echo "fetch pass failed: $W"
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/$W/write -- python3 $CMD > /dev/null 2> $OUT/$W.write.err || echo "write pass failed: $W"
+  echo "done $W"
+done
+python3 $R/tools/pmc_summarize.py $OUT $WL > $OUT/pmc_traffic.json
+cat $OUT/pmc_traffic.json | head -c 3000
