@@ -40,6 +40,18 @@ __global__ void k_build_frags(const float* __restrict__ cb, int M, int K, int ds
     frags[idx] = (j < K && k < dsub) ? cb[((int64_t)m * K + j) * dsub + k] : 0.f;
 }
 
+// Transposed image for the small-codebook VALU kernel (kernels_smallk.hip.h):
+// cbt[m][k][j] = cb[m][j][k] for j < K, 0 for K <= j < KP
+__global__ void k_build_cbt(const float* __restrict__ cb, int M, int K, int dsub, int KP, float* __restrict__ cbt)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)M * dsub * KP) return;
+    const int j = (int)(idx % KP);
+    const int64_t r = idx / KP;
+    const int k = (int)(r % dsub), m = (int)(r / dsub);
+    cbt[idx] = (j < K) ? cb[((int64_t)m * K + j) * dsub + k] : 0.f;
+}
+
 // tells the fast paths whether every centroid norm is finite and far from overflow
 __global__ void k_check_norms(const float* __restrict__ cc, int M, int K, int k_pad, float big,
                               int* __restrict__ flag_bad)

@@ -28,6 +28,7 @@
 #include "kernels_adc.hip.h"
 #include "encode_launch.h"
 #include "opq_fused_launch.h"
+#include "smallk_launch.h"
 
 using namespace pqhip;
 
@@ -114,6 +115,7 @@ struct CodebookDev {
     float* cb = nullptr;     // [M][K][dsub]
     float* frags = nullptr;  // [M][T][S][64]
     float* cc = nullptr;     // [M][k_pad]
+    float* cbt = nullptr;    // [M][dsub][KP] transposed image for the small-codebook kernel (K <= 64)
     float* P = nullptr;      // [d][d]   x.dot(P)
     float* PT = nullptr;     // [d][d]   r.dot(P^T)
     int* err = nullptr;      // [0] unused, [1] "some ||c||^2 not finite" (k_check_norms), [2 .. 2 + kErrSlots):
@@ -141,6 +143,7 @@ struct pqhip_codebook {
     bool has_proj = false;
     // MFMA encode geometry (0 = shape not covered, anchor kernel is used)
     int T = 0, DP = 0, k_pad = 0;
+    int KP = 0;             // small codebooks (K <= 64, instantiated dsub): padded centroid count of the VALU kernel
     int groups = 1;         // K > 256: groups of 256 centroids (8 tiles each) merged through 64-bit keys
     bool norms_ok = false;  // all ||c||^2 finite and < 2^100
     int variant = 0;        // 0 auto, 1 anchor, 2 mfma
@@ -320,6 +323,23 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     CodebookDev& cd = cb->dev[slot];
     if (cb->groups > 1 && cb->variant != 1 && cb->norms_ok && code_bytes == 4)
         return encode_grouped_dev(cb, slot, d_x, n, x_rs, d_codes, o_rs, st);
+    // Small codebooks are HBM-bound: the VALU kernel reads x once and keeps the centroids on the scalar path
+    // (kernels_smallk.hip.h).  Auto choice for K <= 16 (measured +40 % over the MFMA kernel at d = 128, M = 16,
+    // K = 16; at K = 32 / 64 the MFMA kernel is still the faster one) when the host knows the norms are finite;
+    // variant 6 forces it for any K <= 64.
+    if (((cb->variant == 0 && cb->KP == 16) || cb->variant == 6) && cb->KP != 0 && code_bytes == 1 && cb->norms_ok &&
+        bad_flag == nullptr) {
+        SmallKArgs a;
+        a.x = d_x; a.n = n; a.x_rs = x_rs; a.out = (uint8_t*)d_codes; a.o_rs = o_rs;
+        a.cbt = cd.cbt; a.cc = cd.cc; a.cb = cd.cb;
+        a.M = (int)cb->M; a.K = (int)cb->K; a.k_pad = cb->k_pad;
+        const dim3 grid((unsigned)((n + 255) / 256));
+        if (!launch_smallk(cb->KP, (int)cb->dsub, a, grid, st)) return PQHIP_EUNSUPPORTED;
+        HIPCHK(hipGetLastError());
+        cb->last_kernel = "k_encode_smallk";
+        return PQHIP_OK;
+    }
+    if (cb->variant == 6) return PQHIP_EUNSUPPORTED;
     // MFMA kernels: u8 codes from every variant, u32 codes (k-means assignments, wide index types)
     // from the default variant; K <= 256 here (larger K: encode_grouped_dev above, or the anchor)
     const bool mfma_possible = cb->groups == 1 && cb->T != 0 && (cb->norms_ok || bad_flag != nullptr) &&
@@ -478,6 +498,11 @@ int32_t prepare_codebook_dev(pqhip_codebook* cb, int slot, hipStream_t st, bool*
         hipLaunchKernelGGL(k_build_frags, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            cd.cb, (int)M, (int)K, (int)dsub, tiles, S, cd.frags);
     }
+    if (cb->KP) {
+        const int64_t total = M * dsub * cb->KP;
+        hipLaunchKernelGGL(k_build_cbt, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cd.cb, (int)M, (int)K,
+                           (int)dsub, cb->KP, cd.cbt);
+    }
     HIPCHK(hipGetLastError());
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, cd.err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -503,6 +528,11 @@ int32_t prepare_codebook_async(pqhip_codebook* cb, int slot, hipStream_t st)
         const int64_t tot = M * tiles * S * 64;
         hipLaunchKernelGGL(k_build_frags, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
                            cd.cb, (int)M, (int)K, (int)dsub, tiles, S, cd.frags);
+    }
+    if (cb->KP) {
+        const int64_t tot = M * dsub * cb->KP;
+        hipLaunchKernelGGL(k_build_cbt, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, cd.cb, (int)M, (int)K,
+                           (int)dsub, cb->KP, cd.cbt);
     }
     HIPCHK(hipGetLastError());
     return PQHIP_OK;
@@ -543,6 +573,7 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
         }
     }
     cb->T = T; cb->DP = DP; cb->groups = groups;
+    cb->KP = (T != 0 && smallk_has((int)dsub)) ? smallk_kp(K) : 0;
     cb->k_pad = T ? T * 32 * groups : (int)round_up(K, 32);
     const int S = DP / 2;
 
@@ -567,6 +598,7 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
         HIPCHK(hipMalloc((void**)&cd.err, (2 + kErrSlots) * sizeof(int)));
         HIPCHK(hipMemsetAsync(cd.err, 0, (2 + kErrSlots) * sizeof(int), st));
         if (T) HIPCHK(hipMalloc((void**)&cd.frags, (size_t)(M * groups * T * S * 64) * sizeof(float)));
+        if (cb->KP) HIPCHK(hipMalloc((void**)&cd.cbt, (size_t)(M * dsub * cb->KP) * sizeof(float)));
         if (projection) {
             const size_t pb = (size_t)cb->d * cb->d * sizeof(float);
             HIPCHK(hipMalloc((void**)&cd.P, pb));
@@ -1188,6 +1220,7 @@ void pqhip_codebook_destroy(pqhip_codebook* cb)
         if (cd.cb) (void)hipFree(cd.cb);
         if (cd.frags) (void)hipFree(cd.frags);
         if (cd.cc) (void)hipFree(cd.cc);
+        if (cd.cbt) (void)hipFree(cd.cbt);
         if (cd.P) (void)hipFree(cd.P);
         if (cd.PT) (void)hipFree(cd.PT);
         if (cd.err) (void)hipFree(cd.err);
@@ -1206,7 +1239,7 @@ int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && c
 
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {
-    if (!cb || variant < 0 || variant > 5) return PQHIP_EINVAL;
+    if (!cb || variant < 0 || variant > 6) return PQHIP_EINVAL;
     cb->variant = variant;
     return PQHIP_OK;
 }

@@ -1,0 +1,101 @@
+"""The small-codebook encode kernel (K <= 64; kernels_smallk.hip.h): x read once, centroids on the scalar
+path, lane-local first-minimum scan.  Same codes as the oracle (and as the MFMA kernels) for every
+instantiated (padded K, dsub) pair, ragged row counts, strided rows and special values.
+Reference shape: benches/pq.rs:9-10 (d = 128, M = 16, K = 16)."""
+import numpy as np
+import pytest
+
+import synth
+from oracle import pq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import os
+    import reductive_amd
+    if not os.path.exists(reductive_amd.lib_path()):
+        reductive_amd.build()
+    reductive_amd.lib()
+    return reductive_amd
+
+
+@pytest.mark.parametrize("K", [1, 2, 16, 17, 32, 40, 64])
+@pytest.mark.parametrize("dsub", [2, 4, 6, 8, 10, 12, 16, 20, 24, 32])
+def test_every_instantiation_matches_oracle(ra, K, dsub):
+    import torch
+    M = {2: 37, 4: 16, 6: 9, 8: 16, 10: 7, 12: 5, 16: 8, 20: 15, 24: 3, 32: 4}[dsub]
+    n = 3000 + 7 * K + dsub          # ragged: not a multiple of 64
+    q = synth.normalish(7300 + K + dsub, (M, K, dsub))
+    x = synth.normalish(7400 + K + dsub, (n, M * dsub))
+    want = orc.quantize_batch(q, x, n_threads=8)
+    pq = ra.Pq(None, q)
+    pq.set_encode_variant(6)         # auto takes this kernel for K <= 16 only; 6 forces it up to K = 64
+    got = pq.quantize_batch_device(torch.from_numpy(x).cuda())
+    assert pq.last_encode_kernel() == "k_encode_smallk"
+    assert got.cpu().numpy().tobytes() == want.tobytes()
+    auto = ra.Pq(None, q)
+    assert auto.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy().tobytes() == want.tobytes()
+    assert (auto.last_encode_kernel() == "k_encode_smallk") == (K <= 16)
+    pq4 = ra.Pq(None, q)
+    pq4.set_encode_variant(4)        # the MFMA kernel on the same input
+    got4 = pq4.quantize_batch_device(torch.from_numpy(x).cuda())
+    assert pq4.last_encode_kernel().startswith("k_encode_mfma")
+    assert got4.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_reference_bench_shape_special_values_and_strides(ra):
+    import torch
+    M, K, dsub = 16, 16, 8           # benches/pq.rs:9-10
+    d = M * dsub
+    q = synth.normalish(7500, (M, K, dsub))
+    q[3, 5] = q[3, 2]                # duplicate centroids: the lower index wins
+    x = synth.normalish(7501, (100_001, d))
+    x[10, 3] = np.nan
+    x[11, 100] = np.inf
+    x[12] = -np.inf
+    x[13] *= np.float32(1e19)
+    x[14] = 0.0
+    x[15, 24:32] = q[3, 2]           # exact tie between centroids 2 and 5 of sub-vector 3
+    x[100_000, 0] = np.nan
+    pq = ra.Pq(None, q)
+    with np.errstate(all="ignore"):
+        want = orc.quantize_batch(q, x, n_threads=8)
+    got = pq.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert pq.last_encode_kernel() == "k_encode_smallk"
+    assert got.tobytes() == want.tobytes()
+    assert want[15, 3] == 2
+    # strided rows, 4-byte aligned only (row stride d + 3), codes into a wider matrix
+    wide = torch.zeros((5000, d + 3), device="cuda")
+    wide[:, :d] = torch.from_numpy(x[:5000]).cuda()
+    out = torch.zeros((5000, M + 5), device="cuda", dtype=torch.uint8)
+    pq.quantize_batch_device(wide[:, :d], out=out[:, :M])
+    assert out[:, :M].cpu().numpy().tobytes() == want[:5000].tobytes() and int(out[:, M:].sum()) == 0
+    # host-buffer entry point and wider index types
+    assert pq.quantize_batch(x[:20000], dtype=np.uint32).tolist() == want[:20000].astype(np.uint32).tolist()
+
+
+def test_non_finite_codebook_falls_back_and_stays_exact(ra):
+    import torch
+    M, K, dsub = 4, 16, 8
+    q = synth.normalish(7600, (M, K, dsub))
+    q[1, 7, 2] = np.inf
+    x = synth.normalish(7601, (4097, M * dsub))
+    pq = ra.Pq(None, q)
+    with np.errstate(all="ignore"):
+        want = orc.quantize_batch(q, x, n_threads=4)
+    got = pq.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert pq.last_encode_kernel() != "k_encode_smallk"
+    assert got.tobytes() == want.tobytes()
+
+
+def test_kmeans_assignment_uses_it_and_stays_bit_identical(ra):
+    """kmeans::cluster_assignments inside kmeans_iteration (kmeans.rs:319) at K = 16."""
+    import torch
+    n, M, K, dsub = 20000, 16, 16, 8
+    x = synth.normalish(7700, (n, M * dsub))
+    q0 = np.stack([x[np.arange(K) * 97 + m, m * dsub:(m + 1) * dsub] for m in range(M)])
+    got_q, got_loss = ra.kmeans_iterations(q0, torch.from_numpy(x).cuda(), n_iterations=2)
+    want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=2, n_threads=8)
+    assert got_q.tobytes() == want_q.tobytes() and got_loss.tobytes() == want_loss.tobytes()
