@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <mutex>
@@ -52,7 +53,8 @@ thread_local std::string g_hip_err;
         if (s__ != PQHIP_OK) return s__; \
     } while (0)
 
-constexpr int64_t kStageRows = 1 << 16;      // rows per staging buffer (host-resident calls)
+constexpr int64_t kStageBytes = 256ll << 20;   // input bytes per pinned staging buffer of a host-resident call (two per device)
+constexpr int64_t kStageRowsMin = 4096;
 constexpr int64_t kScratchBytesMax = 2ll << 30;   // one leased scratch buffer: <= 2 GiB (larger batches are chunked)
 constexpr int kScratchPoolMax = 4;                // leased scratch buffers per (codebook, device): <= 8 GiB of the 288 GB HBM
 constexpr int kErrSlots = 64;                     // per-stream "code >= K" flags per (codebook, device)
@@ -87,8 +89,82 @@ struct Staging {
     size_t in_bytes = 0, out_bytes = 0;
 };
 
+// A few persistent host threads per device slot: packing strided caller rows into the pinned staging
+// buffers and draining results back is memory-bound work that one core cannot do at PCIe Gen5 speed
+// (~10 GB/s per core against ~55 GB/s).  run() hands out contiguous row ranges and returns when all are done;
+// it is only called under the owning DeviceSlot's mutex.
+class RowPool {
+public:
+    explicit RowPool(int n_threads) : n_(std::max(1, n_threads))
+    {
+        for (int i = 1; i < n_; ++i) th_.emplace_back([this, i] { worker(i); });
+    }
+    ~RowPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    template <typename F>
+    void run(int64_t rows, F fn)
+    {
+        const int nt = (int)std::min<int64_t>(n_, (rows + 1023) / 1024);
+        if (nt <= 1) { fn((int64_t)0, rows); return; }
+        std::function<void(int64_t, int64_t)> f = fn;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &f; rows_ = rows; parts_ = nt; pending_ = nt - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        part(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void part(int i)
+    {
+        const int64_t per = (rows_ + parts_ - 1) / parts_;
+        const int64_t b = std::min<int64_t>(rows_, i * per), e = std::min<int64_t>(rows_, b + per);
+        if (b < e) (*fn_)(b, e);
+    }
+    void worker(int i)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            const bool mine = fn_ != nullptr && i < parts_;
+            lk.unlock();
+            if (mine) {
+                part(i);
+                std::lock_guard<std::mutex> g(mu_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
+    int64_t rows_ = 0;
+    int parts_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
 struct DeviceSlot {
     int ordinal = -1;
+    std::unique_ptr<RowPool> pool;   // created with the context
     std::mutex mu;  // serialises host-resident calls and scratch (re)allocation on this device
     hipStream_t stream[2] = {nullptr, nullptr};
     Staging st[2];
@@ -1054,27 +1130,20 @@ int32_t for_each_shard(pqhip_ctx* ctx, int64_t n, F fn)
     return PQHIP_OK;
 }
 
-// Host-side packing of strided rows into (and out of) the pinned staging buffers runs on a few
-// threads: one core moves ~10 GB/s, PCIe Gen5 x16 ~55 GB/s.
-template <typename F>
-void parallel_rows(int64_t rows, int max_threads, F fn)
-{
-    int nt = (int)std::min<int64_t>(max_threads, (rows + 4095) / 4096);
-    if (nt <= 1) { fn((int64_t)0, rows); return; }
-    std::vector<std::thread> th;
-    const int64_t per = (rows + nt - 1) / nt;
-    for (int t = 0; t < nt; ++t) {
-        const int64_t b = std::min<int64_t>(rows, t * per), e = std::min<int64_t>(rows, b + per);
-        if (b < e) th.emplace_back([=] { fn(b, e); });
-    }
-    for (auto& t : th) t.join();
-}
-
-int pack_threads(const pqhip_ctx* ctx)
+// host threads per device slot for packing / draining (PQHIP_PACK_THREADS overrides; the GPU boxes give a
+// process 16 cores per GPU)
+int pack_threads(size_t n_devs)
 {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    static const unsigned cap = [] { const char* e = getenv("PQHIP_PACK_THREADS"); return e ? (unsigned)std::max(1, atoi(e)) : 8u; }();
-    return (int)std::max<unsigned>(1, std::min<unsigned>(cap, hw / (unsigned)std::max<size_t>(1, ctx->devs.size())));
+    static const unsigned cap = [] { const char* e = getenv("PQHIP_PACK_THREADS"); return e ? (unsigned)std::max(1, atoi(e)) : 16u; }();
+    return (int)std::max<unsigned>(1, std::min<unsigned>(cap, hw / (unsigned)std::max<size_t>(1, n_devs)));
+}
+
+// rows per pinned staging buffer for rows of `row_bytes` input bytes
+int64_t stage_rows(int64_t shard_rows, int64_t row_bytes)
+{
+    const int64_t r = std::max<int64_t>(kStageRowsMin, kStageBytes / std::max<int64_t>(1, row_bytes));
+    return std::max<int64_t>(1, std::min<int64_t>(r, shard_rows));
 }
 
 void store_code(void* base, int bytes, int64_t off, uint32_t v)
@@ -1180,6 +1249,7 @@ int32_t pqhip_ctx_create(const int32_t* devices, int32_t n_devices, pqhip_ctx** 
         SET_DEVICE(o);
         HIPCHK(hipStreamCreateWithFlags(&ds->stream[0], hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&ds->stream[1], hipStreamNonBlocking));
+        ds->pool.reset(new RowPool(pack_threads(ords.size())));
         ctx->devs.push_back(std::move(ds));
     }
     *out = ctx.release();
@@ -1393,24 +1463,35 @@ int32_t pqhip_quantize_batch_f32(pqhip_codebook* cb, const float* x, int64_t n, 
     if (code_bytes < 8 && (uint64_t)(cb->K - 1) > ((1ull << (8 * code_bytes)) - 1)) return PQHIP_EINDEX_WIDTH;
     const int dev_bytes = cb->K <= 256 ? 1 : 4;
     const int64_t d = cb->d, M = cb->M;
-    const int nthreads = pack_threads(cb->ctx);
 
     return for_each_shard(cb->ctx, n, [&](int slot, int64_t rb, int64_t re) -> int32_t {
         DeviceSlot& ds = *cb->ctx->devs[slot];
         std::lock_guard<std::mutex> g(ds.mu);
         SET_DEVICE(ds.ordinal);
-        const int64_t cap = std::min<int64_t>(kStageRows, re - rb);
+        const int64_t cap = stage_rows(re - rb, d * (int64_t)sizeof(float));
         for (int b = 0; b < 2; ++b)
-            PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), (size_t)cap * d * sizeof(float)));
+            PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), (size_t)cap * M * dev_bytes));
         auto drain = [&](int b, int64_t r0, int64_t rows) -> int32_t {
             HIPCHK(hipStreamSynchronize(ds.stream[b]));
             const uint8_t* h8 = (const uint8_t*)ds.st[b].h_out;
             const uint32_t* h32 = (const uint32_t*)ds.st[b].h_out;
-            for (int64_t i = 0; i < rows; ++i)
-                for (int64_t m = 0; m < M; ++m) {
-                    const uint32_t v = dev_bytes == 1 ? h8[i * M + m] : h32[i * M + m];
-                    store_code(codes, code_bytes, (r0 + i) * o_rs + m * o_cs, v);
+            ds.pool->run(rows, [&, r0, h8, h32](int64_t ib, int64_t ie) {
+                if (code_bytes == dev_bytes && o_cs == 1) {           // same width, unit column stride: row copies
+                    char* dst = (char*)codes;
+                    const char* src = (const char*)ds.st[b].h_out;
+                    const size_t rb_ = (size_t)M * dev_bytes;
+                    if (o_rs == M) std::memcpy(dst + (size_t)(r0 + ib) * rb_, src + (size_t)ib * rb_, (size_t)(ie - ib) * rb_);
+                    else
+                        for (int64_t i = ib; i < ie; ++i)
+                            std::memcpy(dst + (size_t)(r0 + i) * o_rs * dev_bytes, src + (size_t)i * rb_, rb_);
+                } else {
+                    for (int64_t i = ib; i < ie; ++i)
+                        for (int64_t m = 0; m < M; ++m) {
+                            const uint32_t v = dev_bytes == 1 ? h8[i * M + m] : h32[i * M + m];
+                            store_code(codes, code_bytes, (r0 + i) * o_rs + m * o_cs, v);
+                        }
                 }
+            });
             return PQHIP_OK;
         };
         int64_t pend_r0[2] = {0, 0}, pend_rows[2] = {0, 0};
@@ -1419,8 +1500,10 @@ int32_t pqhip_quantize_batch_f32(pqhip_codebook* cb, const float* x, int64_t n, 
             const int64_t rows = std::min<int64_t>(cap, re - r0);
             if (pend_rows[b]) { PQCHK(drain(b, pend_r0[b], pend_rows[b])); pend_rows[b] = 0; }
             float* hin = (float*)ds.st[b].h_in;
-            parallel_rows(rows, nthreads, [&, r0, hin](int64_t ib, int64_t ie) {
-                if (x_cs == 1) {
+            ds.pool->run(rows, [&, r0, hin](int64_t ib, int64_t ie) {
+                if (x_cs == 1 && x_rs == d) {
+                    std::memcpy(hin + ib * d, x + (r0 + ib) * d, (size_t)(ie - ib) * d * sizeof(float));
+                } else if (x_cs == 1) {
                     for (int64_t i = ib; i < ie; ++i)
                         std::memcpy(hin + i * d, x + (r0 + i) * x_rs, (size_t)d * sizeof(float));
                 } else {
@@ -1452,20 +1535,21 @@ int32_t pqhip_reconstruct_batch_f32(pqhip_codebook* cb, const void* codes, int32
     if (!codes || !out) return PQHIP_EINVAL;
     const int dev_bytes = code_bytes == 1 ? 1 : 4;
     const int64_t d = cb->d, M = cb->M;
-    const int nthreads = pack_threads(cb->ctx);
 
     return for_each_shard(cb->ctx, n, [&](int slot, int64_t rb, int64_t re) -> int32_t {
         DeviceSlot& ds = *cb->ctx->devs[slot];
         std::lock_guard<std::mutex> g(ds.mu);
         SET_DEVICE(ds.ordinal);
-        const int64_t cap = std::min<int64_t>(kStageRows, re - rb);
+        const int64_t cap = stage_rows(re - rb, d * (int64_t)sizeof(float));   // sized by the OUTPUT rows here
         for (int b = 0; b < 2; ++b)
-            PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), (size_t)cap * d * sizeof(float)));
+            PQCHK(ensure_staging(ds.st[b], (size_t)cap * M * dev_bytes, (size_t)cap * d * sizeof(float)));
         auto drain = [&](int b, int64_t r0, int64_t rows) -> int32_t {
             HIPCHK(hipStreamSynchronize(ds.stream[b]));
             const float* h = (const float*)ds.st[b].h_out;
-            parallel_rows(rows, nthreads, [&, r0, h](int64_t ib, int64_t ie) {
-                if (o_cs == 1) {
+            ds.pool->run(rows, [&, r0, h](int64_t ib, int64_t ie) {
+                if (o_cs == 1 && o_rs == d) {
+                    std::memcpy(out + (r0 + ib) * d, h + ib * d, (size_t)(ie - ib) * d * sizeof(float));
+                } else if (o_cs == 1) {
                     for (int64_t i = ib; i < ie; ++i)
                         std::memcpy(out + (r0 + i) * o_rs, h + i * d, (size_t)d * sizeof(float));
                 } else {
@@ -1477,19 +1561,24 @@ int32_t pqhip_reconstruct_batch_f32(pqhip_codebook* cb, const void* codes, int32
         };
         int64_t pend_r0[2] = {0, 0}, pend_rows[2] = {0, 0};
         int b = 0;
-        bool range_err = false;
+        std::atomic<bool> range_err{false};
         for (int64_t r0 = rb; r0 < re; r0 += cap, b ^= 1) {
             const int64_t rows = std::min<int64_t>(cap, re - r0);
             if (pend_rows[b]) { PQCHK(drain(b, pend_r0[b], pend_rows[b])); pend_rows[b] = 0; }
-            for (int64_t i = 0; i < rows; ++i)
-                for (int64_t m = 0; m < M; ++m) {
-                    const uint64_t c = load_code(codes, code_bytes, (r0 + i) * c_rs + m * c_cs);
-                    if (c >= (uint64_t)cb->K) range_err = true;  // primitives.rs:146 index_axis panic
-                    if (dev_bytes == 1) ((uint8_t*)ds.st[b].h_in)[i * M + m] = (uint8_t)c;
-                    else ((uint32_t*)ds.st[b].h_in)[i * M + m] = (uint32_t)std::min<uint64_t>(c, 0xffffffffull);
-                }
+            void* hin = ds.st[b].h_in;
+            ds.pool->run(rows, [&, r0, hin](int64_t ib, int64_t ie) {
+                bool bad = false;
+                for (int64_t i = ib; i < ie; ++i)
+                    for (int64_t m = 0; m < M; ++m) {
+                        const uint64_t c = load_code(codes, code_bytes, (r0 + i) * c_rs + m * c_cs);
+                        if (c >= (uint64_t)cb->K) bad = true;  // primitives.rs:146 index_axis panic
+                        if (dev_bytes == 1) ((uint8_t*)hin)[i * M + m] = (uint8_t)c;
+                        else ((uint32_t*)hin)[i * M + m] = (uint32_t)std::min<uint64_t>(c, 0xffffffffull);
+                    }
+                if (bad) range_err = true;
+            });
             if (range_err) break;
-            HIPCHK(hipMemcpyAsync(ds.st[b].d_in, ds.st[b].h_in, (size_t)rows * M * dev_bytes,
+            HIPCHK(hipMemcpyAsync(ds.st[b].d_in, hin, (size_t)rows * M * dev_bytes,
                                   hipMemcpyHostToDevice, ds.stream[b]));
             PQCHK(reconstruct_dev_impl(cb, slot, ds.st[b].d_in, dev_bytes, rows, M,
                                        (float*)ds.st[b].d_out, d, ds.stream[b]));
@@ -1569,15 +1658,14 @@ int32_t pqhip_matrix_upload_f32(pqhip_ctx* ctx, int32_t slot, const float* x, in
     SET_DEVICE(ds.ordinal);
     HIPCHK(hipMalloc((void**)&m->d, (size_t)std::max<int64_t>(n, 1) * d * sizeof(float)));
     struct Free { float* p; ~Free() { if (p) (void)hipFree(p); } } guard{m->d};
-    const int64_t cap = std::min<int64_t>(kStageRows, std::max<int64_t>(n, 1));
+    const int64_t cap = stage_rows(std::max<int64_t>(n, 1), d * (int64_t)sizeof(float));
     for (int b = 0; b < 2; ++b) PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), 16));
-    const int nthreads = pack_threads(ctx);
     int b = 0;
     for (int64_t r0 = 0; r0 < n; r0 += cap, b ^= 1) {
         const int64_t rows = std::min<int64_t>(cap, n - r0);
         HIPCHK(hipStreamSynchronize(ds.stream[b]));
         float* hin = (float*)ds.st[b].h_in;
-        parallel_rows(rows, nthreads, [&, r0, hin](int64_t ib, int64_t ie) {
+        ds.pool->run(rows, [&, r0, hin](int64_t ib, int64_t ie) {
             if (x_cs == 1) {
                 for (int64_t i = ib; i < ie; ++i)
                     std::memcpy(hin + i * d, x + (r0 + i) * x_rs, (size_t)d * sizeof(float));

@@ -179,3 +179,35 @@ def test_entry_points_leave_the_callers_current_device_alone(ra):
     assert hip.hipGetDevice(ctypes.byref(cur)) == 0 and cur.value == before
     assert torch.cuda.current_device() == before
     assert L.pqhip_version() == 100
+
+
+@pytest.mark.parametrize("n_slots,M,K,dsub,n", [(2, 48, 256, 16, 40_003), (8, 48, 256, 16, 70_001), (8, 15, 256, 20, 33_000),
+                                               (5, 15, 256, 20, 300_007), (8, 4, 16, 8, 4_097)])
+def test_library_sharder_over_many_device_slots(ra, n_slots, M, K, dsub, n):
+    """SURVEY.md 8e through the LIBRARY's sharder (pqhip_ctx_create(devices) + host-buffer entry points:
+    contiguous row shards, one host thread per slot, codes land in one host array) with up to 8 slots on the
+    one GPU of the box -- the BASELINE configs[4] shape (d = 768, M = 48) included: every row equals the
+    oracle's, wide and strided outputs too."""
+    from reductive_amd.pq import _Ctx
+    ctx = _Ctx(devices=[0] * n_slots)
+    try:
+        assert ctx.n_devices == n_slots
+        d = M * dsub
+        q = synth.normalish(5800 + M, (M, K, dsub))
+        x = synth.normalish(5801 + n, (n, d))
+        pq = ra.Pq(None, q, ctx=ctx)
+        want = orc.quantize_batch(q, x, n_threads=8)
+        assert pq.quantize_batch(x).tobytes() == want.tobytes()
+        wide = np.zeros((n, M + 3), np.uint16)               # strided, wider index type
+        pq.quantize_batch_into(x, wide[:, 1:1 + M])
+        assert wide[:, 1:1 + M].tolist() == want.astype(np.uint16).tolist() and not wide[:, 0].any() and not wide[:, 1 + M:].any()
+        rec = pq.reconstruct_batch(want)
+        assert rec.tobytes() == orc.reconstruct_batch(q, want).tobytes()
+        bad = want.copy()
+        bad[n - 1, M - 1] = K if K < 256 else 0
+        if K < 256:
+            with pytest.raises(ra.PanicError, match="index out of bounds"):
+                pq.reconstruct_batch(bad)                    # the violation sits in the LAST shard
+        pq.close()
+    finally:
+        ctx.close()

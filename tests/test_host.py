@@ -145,18 +145,22 @@ def test_bucket_eigenvalues_kats(ra, kats):
     assert np.abs(P.T @ P - np.eye(6, dtype=np.float32)).max() < 1e-5
 
 
-def test_bench_sharding_two_ranks_gloo():
-    """bench.py's N>1 path on CPU: world_size 2 over gloo, --dry-run (no GPU work):
-    every rank takes its own shard, timing is max-reduced, rank 0 prints one JSON line."""
+@pytest.mark.parametrize("world,workload", [(2, "encode"), (8, "encode_d768")])
+def test_bench_sharding_ranks_gloo(world, workload):
+    """bench.py's N>1 path on CPU: world_size 2 and 8 over gloo, --dry-run (no GPU work): every rank takes
+    its own shard, timing is max-reduced, rank 0 prints one JSON line; the 8-rank case is the BASELINE
+    configs[4] workload (100 M x 768 over 8 GPUs = 12.5 M rows per rank; shrunk rows here)."""
     import json
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--rows", "4096"]
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29531 + world), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--dry-run", "--rows", "4096", "--workload", workload]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["rows_total"] == 8192
-    assert rec["config"]["shards"] == [[0, 4096], [4096, 8192]]
+    assert rec["n_gpus"] == world and rec["scaling"] == "weak" and rec["config"]["rows_total"] == 4096 * world
+    assert rec["config"]["shards"] == [[r * 4096, (r + 1) * 4096] for r in range(world)]
+    if workload == "encode_d768":
+        assert rec["config"]["d"] == 768 and rec["config"]["M"] == 48 and "configs[4]" in rec["config"]["workload"]
