@@ -12,11 +12,10 @@
 #![allow(non_camel_case_types)]
 
 use std::any::TypeId;
-use std::collections::HashMap;
 use std::os::raw::{c_char, c_void};
-use std::sync::{Mutex, Once};
+use std::sync::{Mutex, OnceLock};
 
-use ndarray::{ArrayViewMut3, ArrayBase, ArrayView2, ArrayView3, ArrayViewMut2, Data, Ix2};
+use ndarray::{ArrayBase, ArrayView2, ArrayView3, ArrayViewMut2, ArrayViewMut3, Data, Ix2, ShapeBuilder};
 
 #[repr(C)]
 pub struct pqhip_ctx { _p: [u8; 0] }
@@ -63,41 +62,97 @@ extern "C" {
 /// Batches smaller than this stay on the CPU path (a launch + PCIe round trip is pointless).
 const MIN_GPU_ROWS: usize = 4096;
 
-struct Handles { ctx: *mut pqhip_ctx, books: HashMap<(usize, usize, usize), *mut pqhip_codebook> }
+/// Device images of `Pq<f32>` values, kept OUTSIDE the struct so that `Pq` keeps
+/// `#[derive(Clone, Debug, PartialEq)]` and literal construction (pq.rs:28-32, opq.rs:95-98).
+/// Same policy as include/reductive_amd/codebook_cache.hpp (which the test-suite executes,
+/// tests/cpp/test_codebook_cache.cpp):
+///  * key = (quantizer data pointer, element count, ORIGINAL projection data pointer or 0, M, K, dsub)
+///    -- never the address of a temporary copy;
+///  * a hit is trusted only when a 64-bit content hash of quantizers + projection still matches: a
+///    dropped `Pq` whose allocation is reused, or centroids mutated in place during training, replace
+///    the entry (the stale device image is destroyed) instead of returning wrong codes;
+///  * at most `CACHE_CAP` entries, least recently used destroyed: device memory stays bounded.
+const CACHE_CAP: usize = 8;
+#[derive(PartialEq, Clone, Copy)]
+struct Key { q: usize, q_len: usize, p: usize, m: usize, k: usize, dsub: usize }
+struct Entry { key: Key, hash: u64, cb: *mut pqhip_codebook }
+struct Handles { ctx: *mut pqhip_ctx, books: Vec<Entry> /* most recently used first */ }
 unsafe impl Send for Handles {}
-static INIT: Once = Once::new();
-static mut HANDLES: Option<Mutex<Handles>> = None;
+static HANDLES: OnceLock<Option<Mutex<Handles>>> = OnceLock::new();
 
 fn handles() -> Option<&'static Mutex<Handles>> {
-    unsafe {
-        INIT.call_once(|| {
-            let mut ctx = std::ptr::null_mut();
-            if pqhip_ctx_create(std::ptr::null(), 0, &mut ctx) == PQHIP_OK {
-                HANDLES = Some(Mutex::new(Handles { ctx, books: HashMap::new() }));
-            }
-        });
-        HANDLES.as_ref()
-    }
+    HANDLES.get_or_init(|| {
+        let mut ctx = std::ptr::null_mut();
+        if unsafe { pqhip_ctx_create(std::ptr::null(), 0, &mut ctx) } == PQHIP_OK {
+            Some(Mutex::new(Handles { ctx, books: Vec::new() }))
+        } else { None }
+    }).as_ref()
 }
 
-/// Device image of a `Pq<f32>`, cached by the identity (data pointers + len) of its arrays so that
-/// `Pq` keeps `#[derive(Clone, Debug, PartialEq)]` and literal construction (pq.rs:28-32, opq.rs:95-98).
-fn codebook(q: ArrayView3<f32>, p: Option<ArrayView2<f32>>) -> Option<*mut pqhip_codebook> {
-    let q = q.as_standard_layout();
-    let p = p.map(|p| p.as_standard_layout().into_owned());
-    let key = (q.as_ptr() as usize, q.len(), p.as_ref().map_or(0, |p| p.as_ptr() as usize));
+/// FNV-1a over 8-byte words: change detection, not cryptography (content_hash of codebook_cache.hpp).
+fn content_hash(data: &[f32], mut h: u64) -> u64 {
+    let bytes = unsafe { std::slice::from_raw_parts(data.as_ptr() as *const u8, data.len() * 4) };
+    let mut chunks = bytes.chunks_exact(8);
+    for c in &mut chunks {
+        h = (h ^ u64::from_ne_bytes(c.try_into().unwrap())).wrapping_mul(0x100000001b3);
+        h ^= h >> 29;
+    }
+    for &b in chunks.remainder() { h = (h ^ b as u64).wrapping_mul(0x100000001b3); }
+    h
+}
+
+/// Runs `f` with the device image of (quantizers, projection) while the cache lock is held, so the
+/// handle cannot be evicted under the call.  `None` => no device / creation failed => CPU path.
+fn with_codebook<R>(q: ArrayView3<f32>, p: Option<ArrayView2<f32>>, f: impl FnOnce(*mut pqhip_codebook) -> R) -> Option<R> {
+    // contiguous copies only when the views are not in standard layout; the KEY uses the caller's pointers
+    let key_q = q.as_ptr() as usize;
+    let key_p = p.as_ref().map_or(0, |p| p.as_ptr() as usize);
+    let qs = q.as_standard_layout();
+    let ps = p.as_ref().map(|p| p.as_standard_layout());
+    let (m, k, dsub) = qs.dim();
+    let key = Key { q: key_q, q_len: qs.len(), p: key_p, m, k, dsub };
+    let mut hash = content_hash(qs.as_slice()?, 0xcbf29ce484222325);
+    if let Some(ps) = &ps { hash = content_hash(ps.as_slice()?, hash); }
     let mut h = handles()?.lock().ok()?;
-    if let Some(cb) = h.books.get(&key) { return Some(*cb); }
-    let (m, k, dsub) = q.dim();
+    if let Some(i) = h.books.iter().position(|e| e.key == key) {
+        if h.books[i].hash == hash {
+            let e = h.books.remove(i);
+            h.books.insert(0, e);
+            return Some(f(h.books[0].cb));
+        }
+        let stale = h.books.remove(i);                 // same address, other contents
+        unsafe { pqhip_codebook_destroy(stale.cb) };
+    }
     let mut cb = std::ptr::null_mut();
-    let rc = unsafe { pqhip_codebook_create(h.ctx, q.as_ptr(), m as i64, k as i64, dsub as i64,
-        p.as_ref().map_or(std::ptr::null(), |p| p.as_ptr()), &mut cb) };
+    let rc = unsafe { pqhip_codebook_create(h.ctx, qs.as_ptr(), m as i64, k as i64, dsub as i64,
+        ps.as_ref().map_or(std::ptr::null(), |p| p.as_ptr()), &mut cb) };
     if rc != PQHIP_OK { return None; }
-    h.books.insert(key, cb);
-    Some(cb)
+    h.books.insert(0, Entry { key, hash, cb });
+    while h.books.len() > CACHE_CAP {
+        let old = h.books.pop().unwrap();
+        unsafe { pqhip_codebook_destroy(old.cb) };
+    }
+    Some(f(cb))
 }
 
 fn same<A: 'static, B: 'static>() -> bool { TypeId::of::<A>() == TypeId::of::<B>() }
+
+/// Reinterpret an `ArrayView<A>` as `ArrayView<f32>` once `A == f32` has been established with `TypeId`.
+/// (A `transmute` between the two view types is rejected for a generic `A` -- E0512, the sizes are not
+/// known to be equal -- so the view is rebuilt from its raw parts: same pointer, shape and strides.)
+unsafe fn view3_as_f32<'a, A: 'static>(v: ArrayView3<'a, A>) -> ArrayView3<'a, f32> {
+    debug_assert!(same::<A, f32>());
+    let (d0, d1, d2) = v.dim();
+    let s = v.strides();
+    ArrayView3::from_shape_ptr((d0, d1, d2).strides((s[0] as usize, s[1] as usize, s[2] as usize)), v.as_ptr() as *const f32)
+}
+unsafe fn view2_as_f32<'a, A: 'static>(v: ArrayView2<'a, A>) -> ArrayView2<'a, f32> {
+    debug_assert!(same::<A, f32>());
+    let (d0, d1) = v.dim();
+    let s = v.strides();
+    ArrayView2::from_shape_ptr((d0, d1).strides((s[0] as usize, s[1] as usize)), v.as_ptr() as *const f32)
+}
+fn non_negative(strides: &[isize]) -> bool { strides.iter().all(|&s| s >= 0) }
 
 /// Returns true when the GPU produced the result; false => caller runs `primitives::*` unchanged.
 /// The shape asserts of primitives.rs:74-87 are performed by the caller BEFORE this call, so panic
@@ -109,15 +164,17 @@ where A: 'static + Copy, I: 'static + Copy, S: Data<Elem = A>,
     if !same::<A, f32>() || x.nrows() < MIN_GPU_ROWS { return false; }
     let code_bytes = std::mem::size_of::<I>() as i32;
     if !(same::<I, u8>() || same::<I, u16>() || same::<I, u32>() || same::<I, u64>() || same::<I, usize>()) { return false; }
-    // SAFETY: A == f32 was checked above.
-    let (q, p, x): (ArrayView3<f32>, Option<ArrayView2<f32>>, ArrayView2<f32>) = unsafe {
-        (std::mem::transmute(quantizers), std::mem::transmute(projection), std::mem::transmute(x.view()))
-    };
-    let cb = match codebook(q, p) { Some(cb) => cb, None => return false };
+    if !non_negative(quantizers.strides()) || projection.as_ref().map_or(false, |p| !non_negative(p.strides())) { return false; }
     let (xs, qs) = (x.strides(), quantized.strides());
-    if xs.iter().chain(qs.iter()).any(|&s| s < 0) { return false; }
-    let rc = unsafe { pqhip_quantize_batch_f32(cb, x.as_ptr(), x.nrows() as i64, xs[0] as i64, xs[1] as i64,
-        quantized.as_mut_ptr() as *mut c_void, code_bytes, qs[0] as i64, qs[1] as i64) };
+    if !non_negative(xs) || !non_negative(qs) { return false; }
+    // SAFETY: A == f32 was checked above; pointer, shape and strides are carried over unchanged.
+    let (q, p) = unsafe { (view3_as_f32(quantizers), projection.map(|p| view2_as_f32(p))) };
+    let (x_ptr, n) = (x.as_ptr() as *const f32, x.nrows() as i64);
+    let out = quantized.as_mut_ptr() as *mut c_void;
+    let rc = with_codebook(q, p, |cb| unsafe {
+        pqhip_quantize_batch_f32(cb, x_ptr, n, xs[0] as i64, xs[1] as i64, out, code_bytes, qs[0] as i64, qs[1] as i64)
+    });
+    let rc = match rc { Some(rc) => rc, None => return false };
     // EINDEX_WIDTH: K-1 > I::MAX. The reference's batch path wraps silently (primitives.rs:98-100);
     // fall back so that (odd) behaviour is preserved bit for bit.
     rc == PQHIP_OK
@@ -129,14 +186,18 @@ where A: 'static + Copy, I: 'static + Copy, S: Data<Elem = I>,
 {
     if !same::<A, f32>() || quantized.nrows() < MIN_GPU_ROWS { return false; }
     if !(same::<I, u8>() || same::<I, u16>() || same::<I, u32>() || same::<I, u64>() || same::<I, usize>()) { return false; }
-    let (q, p): (ArrayView3<f32>, Option<ArrayView2<f32>>) =
-        unsafe { (std::mem::transmute(quantizers), std::mem::transmute(projection)) };
-    let cb = match codebook(q, p) { Some(cb) => cb, None => return false };
+    if !non_negative(quantizers.strides()) || projection.as_ref().map_or(false, |p| !non_negative(p.strides())) { return false; }
     let (cs, os) = (quantized.strides(), reconstructions.strides());
-    if cs.iter().chain(os.iter()).any(|&s| s < 0) { return false; }
-    let rc = unsafe { pqhip_reconstruct_batch_f32(cb, quantized.as_ptr() as *const c_void,
-        std::mem::size_of::<I>() as i32, quantized.nrows() as i64, cs[0] as i64, cs[1] as i64,
-        reconstructions.as_mut_ptr() as *mut f32, os[0] as i64, os[1] as i64) };
+    if !non_negative(cs) || !non_negative(os) { return false; }
+    // SAFETY: A == f32 was checked above.
+    let (q, p) = unsafe { (view3_as_f32(quantizers), projection.map(|p| view2_as_f32(p))) };
+    let (c_ptr, n) = (quantized.as_ptr() as *const c_void, quantized.nrows() as i64);
+    let out = reconstructions.as_mut_ptr() as *mut f32;
+    let rc = with_codebook(q, p, |cb| unsafe {
+        pqhip_reconstruct_batch_f32(cb, c_ptr, std::mem::size_of::<I>() as i32, n, cs[0] as i64, cs[1] as i64,
+                                    out, os[0] as i64, os[1] as i64)
+    });
+    let rc = match rc { Some(rc) => rc, None => return false };
     if rc == PQHIP_ECODE_RANGE { panic!("ndarray: index out of bounds"); }   // primitives.rs:146
     rc == PQHIP_OK
 }

@@ -32,3 +32,31 @@ def test_cpp_mirror_on_gpu(tmp_path):
     out = subprocess.run([_build(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed (GPU)" in out.stdout
+
+
+def _build_cache_test(tmp_path):
+    import reductive_amd
+    if not os.path.exists(reductive_amd.lib_path()):
+        reductive_amd.build()
+    exe = str(tmp_path / "test_codebook_cache")
+    libdir = os.path.join(ROOT, "reductive_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_codebook_cache.cpp"),
+                           "-L", libdir, "-lpqhip", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_codebook_cache_policy(tmp_path):
+    """The device-codebook cache of the reference-side binding (rust/pqhip_ffi.rs mirrors
+    include/reductive_amd/codebook_cache.hpp): content-validated hits, stale images replaced, bounded."""
+    out = subprocess.run([_build_cache_test(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "cache policy checks passed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_codebook_cache_never_serves_a_stale_device_image(tmp_path):
+    out = subprocess.run([_build_cache_test(tmp_path), "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all checks passed (GPU)" in out.stdout
