@@ -1,6 +1,7 @@
 // kernels_rotate.hip.h -- OPQ rotation GEMM and the MFMA self-test (non-template kernels: include
 // from exactly one translation unit, pqhip.hip).
 #pragma once
+#include <type_traits>
 #include "kernels_mfma.hip.h"
 
 namespace pqhip {
@@ -484,6 +485,230 @@ __global__ __launch_bounds__(512, 2) void k_rotate_pblock5(const float* __restri
             }
         }
         if (has_next) stash(0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2/K4 v6  rotation GEMM, P-block stationary, THREE waves per SIMD.
+// Same data flow as v5 -- a 64-column block of Pm for all k in LDS, wave-private x slabs staged in the
+// (k0, k2, k1, k3) order and consumed by ds_read_b64 -- with two changes that the in-kernel stamps of
+// round 2 asked for (v5 at two waves per SIMD: k loop 48 k cycles per 32-row tile against 38.4 k of
+// matrix issue, plus a 7-8 k cycle MFMA-free tile epilogue that two lock-stepped waves cannot hide):
+//   * 12 waves per workgroup instead of 8.  The third wave per SIMD covers the other two's epilogues and
+//     LDS / HBM waits.  To fit, a slab is 16 k deep ([32 rows][16 k], 2 x 2.5 KB per wave) and the P image
+//     has exactly ceil(d / 4) groups: 76.8 + 61.4 KB of LDS at d = 300; <= 168 VGPRs.
+//   * the LDS operands of group u + 1 are requested before the four MFMAs of group u are issued, across
+//     slab boundaries too (two statically named operand sets);
+// Stamps (PQHIP_DEBUG_ROT_STAMP, 10 M x 300, clock 2.24 GHz under this load): k loop 64 k + epilogue 8.5 k
+// cycles per tile and wave where three waves sharing a SIMD need 57.6 k of matrix issue (79 %); 9 % of the
+// launch lies outside the tile loops (P staging per workgroup, workgroup turnover, chunk tails).  Measured
+// equal to v5 within 1 % (34.1-34.5 vs 34.3-34.8 ms for rotate + encode of 10 M rows); starting the three
+// waves of a SIMD a third of a tile apart changed nothing.
+// Requires 16-byte aligned rows and d % 4 == 0, like v5.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768, 3) void k_rotate_pblock6(const float* __restrict__ x, int64_t n,
+                                                           int64_t x_rs, const float* __restrict__ Pm,
+                                                           int d, float* __restrict__ out, int64_t o_rs,
+                                                           int rows_per_wg, int ncb, int64_t rg_per_xcd,
+                                                           unsigned long long* stamps /* diagnostics: PQHIP_DEBUG_ROT_STAMP */)
+{
+    constexpr int NWAVE = 12;
+    constexpr int KS = 16;                       // k per slab (4 groups of 4)
+    constexpr int XS = 20;                       // slab row stride in floats (80 B: 16-B aligned)
+    constexpr int OS = 36;                       // row stride of the output staging image (both slab buffers: 2 x 640 >= 32 x 36 floats)
+    extern __shared__ __attribute__((aligned(16))) float smem6[];
+    const int ngroups = (d + 3) >> 2;
+    float* pl = smem6;                           // [ngroups][64 cols][4]
+    float* xs_all = smem6 + (size_t)ngroups * 256;   // [12 waves][2][32][XS]  (2 x 640 floats per wave)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t q = b >> 3;
+    const int cb = (int)(q % ncb);
+    const int64_t rg_local = q / ncb;
+    const int64_t rg = rg_local * 8 + xcd;
+    const int col0 = cb * 64;
+
+    // stage the P block: 16-byte loads, two in flight per thread before the LDS stores
+    {
+        const int total = d * 16;                // float4 per block: d rows x 16
+        for (int i0 = tid; i0 < total; i0 += 768 * 2) {
+            f32x4 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = i0 + 768 * u;
+                const int k = idx >> 4, c = col0 + 4 * (idx & 15);
+                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (idx < total && c < d) v[u] = *reinterpret_cast<const f32x4*>(Pm + (int64_t)k * d + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = i0 + 768 * u;
+                if (idx < total) {
+                    const int k = idx >> 4, c4 = idx & 15;
+                    const int inner = ((k & 1) << 1) | ((k >> 1) & 1);
+                    float* dst = pl + ((((k >> 2) << 6) + 4 * c4) << 2) + inner;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[4 * e] = v[u][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (rg_local >= rg_per_xcd) return;
+    const int64_t wg_row0 = rg * rows_per_wg;
+    if (wg_row0 >= n) return;
+    int64_t wg_row1 = wg_row0 + rows_per_wg;
+    if (wg_row1 > n) wg_row1 = n;
+
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                         0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float* xs = xs_all + (size_t)wave * 2 * 32 * XS;
+    const float* plane = pl + 4 * j + 2 * h;     // + q * 256 floats per group; + 128: second column tile
+    const int nslab = (d + KS - 1) / KS;
+    const int tail_groups = (d - KS * (nslab - 1) + 3) / 4;  // 4-k groups with real k in the last slab (1..4)
+    constexpr int SB = kKC / KS;                 // slabs per rule-2 block
+    const int lr = lane >> 2, lc = lane & 3;     // staging role: rows lr + 16 i (i = 0, 1), 16-byte piece lc
+
+    const float* rp[2];
+    auto set_rows = [&](int64_t row0) {
+        const int left = (int)((n - row0 < 32) ? n - row0 : 32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = lr + 16 * i;
+            rp[i] = x + ((r < left) ? row0 + r : n - 1) * x_rs + 4 * lc;
+        }
+    };
+    f32x4 st[2];
+    auto fetch = [&](int slab) {                 // 4 lanes x 16 B = 64 contiguous bytes of one row
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = KS * slab + 4 * lc;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < d) v = *reinterpret_cast<const f32x4*>(rp[i] + KS * slab);
+            st[i] = v;
+        }
+    };
+    auto stash = [&](int buf) {                  // (k0, k1, k2, k3) -> (k0, k2, k1, k3)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 w = {st[i][0], st[i][2], st[i][1], st[i][3]};
+            *reinterpret_cast<f32x4*>(xs + ((size_t)buf * 32 + lr + 16 * i) * XS + 4 * lc) = w;
+        }
+    };
+
+    // k loop, straight-line per slab.  Operand registers ping-pong between two sets (A, B): the LDS reads of
+    // group u + 1 are in flight while the four MFMAs of group u issue, ACROSS slab boundaries too -- slab
+    // s + 1 is already in LDS when slab s starts (it was fetched during slab s - 1 and is stored first thing
+    // in slab s), so the last group of a slab pre-reads the first group of the next one.  (The first build
+    // of this kernel rotated one register set through copies inside a loop with run-time trip counts: the
+    // compiler then waited lgkmcnt(0) in front of every group's MFMAs and the prefetch hid nothing.)
+    const int nfull = (d % KS == 0) ? nslab : nslab - 1;     // slabs with all four groups
+    auto xaddr = [&](int slab) { return xs + ((size_t)(slab & 1) * 32 + j) * XS + 2 * h; };
+    f32x2 xa, pa0, pa1, xb, pb0, pb1;
+#define PQ6_RD(X, P0, P1, SLAB, U)                                                  \
+    {                                                                               \
+        const float* ar_ = xaddr(SLAB) + 4 * (U);                                   \
+        const float* pq_ = plane + ((SLAB) * (KS / 4) + (U)) * 256;                 \
+        X = *reinterpret_cast<const f32x2*>(ar_);                                   \
+        P0 = *reinterpret_cast<const f32x2*>(pq_);                                  \
+        P1 = *reinterpret_cast<const f32x2*>(pq_ + 128);                            \
+    }
+#define PQ6_MM(X, P0, P1)                                                           \
+    {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(X[0], P0[0], c0, 0, 0, 0);        \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(X[0], P1[0], c1, 0, 0, 0);        \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(X[1], P0[1], c0, 0, 0, 0);        \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(X[1], P1[1], c1, 0, 0, 0);        \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    }
+
+    int64_t row0 = wg_row0 + 32 * wave;
+    if (row0 >= wg_row1) return;
+    set_rows(row0);
+    fetch(0);
+    stash(0);
+    if (nslab > 1) fetch(1);                     // st: slab 1, stored in mid-slab 0
+    unsigned long long st_tiles = 0, st_k = 0, st_e = 0;
+    const unsigned long long st_t0 = stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+    for (; row0 < wg_row1; row0 += 32 * NWAVE) {
+        const unsigned long long st_a = stamps ? __builtin_amdgcn_s_memtime() : 0;
+        const int left = (int)((n - row0 < 32) ? n - row0 : 32);
+        f32x16 tot0 = zero, tot1 = zero;
+        PQ6_RD(xa, pa0, pa1, 0, 0);
+        for (int sb = 0; sb < nslab; sb += SB) {             // rule-2 blocks of 256 k
+            const int se = (sb + SB < nslab) ? sb + SB : nslab;
+            f32x16 c0 = zero, c1 = zero;
+            for (int slab = sb; slab < se; ++slab) {
+                if (slab < nfull) {
+                    PQ6_RD(xb, pb0, pb1, slab, 1);
+                    PQ6_MM(xa, pa0, pa1);
+                    // slab + 1 (requested one slab ago) goes to LDS in mid-slab: nothing but the pre-read of
+                    // the first group is outstanding at the loop head, and the store is long retired when the
+                    // last group pre-reads the next slab
+                    if (slab + 1 < nslab) stash((slab + 1) & 1);
+                    if (slab + 2 < nslab) fetch(slab + 2);
+                    PQ6_RD(xa, pa0, pa1, slab, 2);
+                    PQ6_MM(xb, pb0, pb1);
+                    PQ6_RD(xb, pb0, pb1, slab, 3);
+                    PQ6_MM(xa, pa0, pa1);
+                    if (slab + 1 < nslab) PQ6_RD(xa, pa0, pa1, slab + 1, 0);
+                    PQ6_MM(xb, pb0, pb1);
+                } else {                         // last, partial slab: 1 .. 3 groups (wave-uniform)
+                    PQ6_RD(xb, pb0, pb1, slab, 1);   // (reads past the last real group stay inside LDS, unused)
+                    PQ6_MM(xa, pa0, pa1);
+                    if (tail_groups > 1) {
+                        PQ6_RD(xa, pa0, pa1, slab, 2);
+                        PQ6_MM(xb, pb0, pb1);
+                    }
+                    if (tail_groups > 2) PQ6_MM(xa, pa0, pa1);
+                }
+            }
+            if (sb == 0) { tot0 = c0; tot1 = c1; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { tot0[r] = fadd(tot0[r], c0[r]); tot1[r] = fadd(tot1[r], c1[r]); }
+            }
+        }
+        unsigned long long st_b = 0;
+        if (stamps) { asm volatile("" ::"v"(tot0), "v"(tot1)); st_b = __builtin_amdgcn_s_memtime(); }
+        // the next tile's first slab starts its trip from HBM before the stores of this one
+        const bool has_next = row0 + 32 * NWAVE < wg_row1;
+        if (has_next) { set_rows(row0 + 32 * NWAVE); fetch(0); }
+        // epilogue: the 32 x 64 result goes through the wave's (now free) slab buffers so that every lane
+        // stores 16 contiguous bytes.  (Leaving the tile in its registers and storing it as dwords during
+        // the next k loop -- two 128-byte row segments per instruction, no extra registers -- was tried:
+        // 64 predicated stores per tile made the k loop 30 % longer.)
+        float* os = xs;
+        const int er = lane >> 3, ec = lane & 7;     // rows er + 8 i, 16-byte piece ec of a 32-column tile
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                os[((r & 3) + 8 * (r >> 2) + 4 * h) * OS + j] = ct ? tot1[r] : tot0[r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = er + 8 * i;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(os + rr * OS + 4 * ec);
+                const int col = col0 + 32 * ct + 4 * ec;
+                if (rr < left && col < d)
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (row0 + rr) * o_rs + col));
+            }
+        }
+        if (has_next) { stash(0); if (nslab > 1) fetch(1); }
+        if (stamps) { const unsigned long long st_c = __builtin_amdgcn_s_memtime(); st_tiles += 1; st_k += st_b - st_a; st_e += st_c - st_b; }
+    }
+#undef PQ6_RD
+#undef PQ6_MM
+    if (stamps && lane == 0) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * NWAVE + wave) * 5;
+        o[0] = st_tiles; o[1] = st_k; o[2] = st_e;
+        o[3] = __builtin_amdgcn_s_memtime() - st_t0; o[4] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
 }
 

@@ -491,6 +491,16 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     return PQHIP_OK;
 }
 
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int32_t alloc(size_t bytes)
+    {
+        HIPCHK(hipMalloc(&p, bytes ? bytes : 1));
+        return PQHIP_OK;
+    }
+};
+
 // out[n][d] = x[n][d] . Pm   on the device
 int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, int d, float* d_out,
                    int64_t o_rs, hipStream_t st)
@@ -499,6 +509,42 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
     const bool vec = (d % 4 == 0) && (x_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
     const int kpad = (d + 3) & ~3;
     const size_t pblock_bytes = (size_t)kpad * 64 * sizeof(float);
+    {
+        // v6: as v5 with three waves per SIMD (12-wave workgroups, 16-k slabs)
+        const size_t lds6 = ((size_t)((d + 3) / 4) * 256 + (size_t)12 * 2 * 32 * 20) * sizeof(float);
+        static const bool use_v6 = getenv("PQHIP_DEBUG_NO_GEMM6") == nullptr;
+        const bool out_vec6 = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
+        if (use_v6 && vec && out_vec6 && lds6 <= 160 * 1024) {
+            const int rows_per_wg = 12 * 32 * 12;     // 12 tiles per wave
+            const int ncb = (d + 63) / 64;
+            const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
+            const int64_t rg_per_xcd = (n_rg + 7) / 8;
+            const dim3 grid((unsigned)(rg_per_xcd * ncb * 8));
+            HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock6, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            static const bool want_stamps = getenv("PQHIP_DEBUG_ROT_STAMP") != nullptr;
+            DevBuf stamp_buf;
+            const size_t n_stamp = (size_t)grid.x * 12 * 5;
+            if (want_stamps) {
+                PQCHK(stamp_buf.alloc(n_stamp * sizeof(unsigned long long)));
+                HIPCHK(hipMemsetAsync(stamp_buf.p, 0, n_stamp * sizeof(unsigned long long), st));
+            }
+            hipLaunchKernelGGL(k_rotate_pblock6, grid, dim3(768), lds6, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, rg_per_xcd,
+                               (unsigned long long*)stamp_buf.p);
+            HIPCHK(hipGetLastError());
+            if (want_stamps) {   // diagnostics: synchronous summary on stderr
+                std::vector<unsigned long long> h(n_stamp);
+                HIPCHK(hipMemcpyAsync(h.data(), stamp_buf.p, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                double tiles = 0, kc = 0, ec = 0, cyc = 0, rt = 0; size_t waves = 0;
+                for (size_t i = 0; i < n_stamp; i += 5)
+                    if (h[i]) { tiles += (double)h[i]; kc += (double)h[i + 1]; ec += (double)h[i + 2]; cyc += (double)h[i + 3]; rt += (double)h[i + 4]; ++waves; }
+                if (tiles > 0)
+                    fprintf(stderr, "[pqhip] rotate v6 stamps: %zu waves, %.1f tiles/wave, k loop %.0f cyc/tile, epilogue %.0f cyc/tile, wave life %.0f cyc, clock %.0f MHz\n",
+                            waves, tiles / waves, kc / tiles, ec / tiles, cyc / waves, rt > 0 ? cyc / rt * 100.0 : 0.0);
+            }
+            return PQHIP_OK;
+        }
+    }
     {
         // v5: P block + wave-private x slabs in LDS, one 8-wave workgroup per CU
         const int kpad32 = (d + 31) & ~31;
@@ -692,15 +738,6 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
     return PQHIP_OK;
 }
 
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int32_t alloc(size_t bytes)
-    {
-        HIPCHK(hipMalloc(&p, bytes ? bytes : 1));
-        return PQHIP_OK;
-    }
-};
 
 int32_t ensure_ws(DeviceSlot& ds, int i, size_t bytes)
 {
