@@ -44,6 +44,8 @@ struct EncodeArgs {
     // every row takes the exact path.  Lets a captured k-means iteration (hipGraph) stay correct
     // without the host looking at the flag between iterations.  nullptr: the host has checked.
     const int* bad_flag;
+    // diagnostics only (PQHIP_DEBUG_ENC_STAMP): per wave {tiles, step-loop cycles, seam cycles, wave cycles, realtime ticks}
+    unsigned long long* stamps = nullptr;
 };
 
 // Order-preserving map of an f32 distance onto u32 under ordered-float's total order

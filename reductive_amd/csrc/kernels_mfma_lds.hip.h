@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
 {
     constexpr int S = DP / 2;
     __shared__ __attribute__((aligned(16))) float afrag_s[T][S][64];
-    __shared__ __attribute__((aligned(16))) long long slot_s[4][T][64];
+    __shared__ __attribute__((aligned(16))) long long slot_s[4][T + 1][64];   // [T]: the tile fold's target
     __shared__ __attribute__((aligned(16))) float cc_s[T * 32];
 
     const int lane = threadIdx.x & 63;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
         const float* ccm = a.cc + (int64_t)m * T * 32;
         for (int i = threadIdx.x; i < T * 32; i += 256) cc_s[i] = ccm[i];
 #pragma unroll
-        for (int t = 0; t < T; ++t) slot_s[wave][t][lane] = kKeyInit;
+        for (int t = 0; t <= T; ++t) slot_s[wave][t][lane] = kKeyInit;
     }
     __syncthreads();
     const int64_t row_begin = (group * 4 + wave) * a.rows_per_item;
@@ -74,38 +74,96 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
     const float* xcol = a.x + (int64_t)m_real * a.dsub;
     const bool bad_codebook = a.bad_flag != nullptr && *a.bad_flag != 0;  // wave-uniform
 
-    // x tile: lane j reads the DP floats of its row's sub-vector.  Rows past the end are clamped
-    // to the last row (their result is never stored).
-    const float* const plast = xcol + (a.n - 1) * a.x_rs;
-    auto load_tile = [&](f32x2 (&v2)[DP / 2], int64_t tile_row0) {
+    // x tile.  SPLIT (every float real, DP a multiple of 4): lane (row j, half h) fetches only floats
+    // [h DP/2, (h + 1) DP/2) of its row's sub-vector -- half the load traffic of "both halves read the whole
+    // sub-vector" -- and one v_permlane32_swap per register pair turns (x[2i], x[2i+1] | x[DP/2+2i], x[DP/2+2i+1])
+    // into the MFMA B operands of k-steps i and DP/4 + i (half 0: k = 2s, half 1: k = 2s + 1): no lane-half
+    // selects.  ||x||^2 (rule 1) is then summed across the halves, the adds in ndarray's order.
+    // Otherwise: lane j reads the DP floats of its row's sub-vector (both halves the same bytes).
+    // Rows past the end are clamped to the last row (their result is never stored).
+    constexpr bool SPLIT = VEC && (DP % 4 == 0) && DP <= 32;
+    constexpr int NV2 = SPLIT ? DP / 4 : DP / 2;            // float pairs a lane holds per tile
+    const float* const plast = xcol + (a.n - 1) * a.x_rs + (SPLIT ? h * (DP / 2) : 0);
+    const float* prow = xcol + (row_begin + j) * a.x_rs + (SPLIT ? h * (DP / 2) : 0);   // this lane's row of the tile being loaded
+    const int64_t tile_step = 32 * a.x_rs;
+    auto load_tile = [&](f32x2 (&v2)[NV2], int64_t tile_row0) {
         const int left = (int)((a.n - tile_row0 < 32) ? a.n - tile_row0 : 32);  // wave-uniform
-        const float* p = (j < left) ? xcol + (tile_row0 + j) * a.x_rs : plast;
-        // VEC: all DP floats are real (dsub == DP).  Otherwise: DP <= 32 -> dsub == DP - 1 and the
-        // last one is padding; DP > 32 (wide sub-vectors, DP a multiple of 8) -> run-time dsub < DP
-        float v[DP];
-        if (VEC || DP <= 32) load_row_floats<VEC ? DP : DP - 1, DP>(p, v);
-        else load_row_floats_rt<DP>(p, a.dsub, v);
+        const float* p = (j < left) ? prow : plast;
+        if constexpr (SPLIT) {
+            float v[DP / 2];
+            load_row_floats<DP / 2, DP / 2>(p, v);
 #pragma unroll
-        for (int e = 0; e < DP; e += 2) v2[e / 2] = (f32x2){v[e], v[e + 1]};
-    };
-    auto prep_tile = [&](const f32x2 (&v2)[DP / 2], float (&bop)[S], float& xx) {
-        // the sub-dimension is a compile-time fact (DP or DP - 1): with a run-time test the compiler
-        // if-converts and executes BOTH norm variants for every tile (~100 VALU)
-        if (VEC) {
-            xx = norm_unrolled_packed<DP>(v2);
-        } else if (DP <= 32) {
-            float v[DP - 1];
-#pragma unroll
-            for (int e = 0; e < DP - 1; ++e) v[e] = v2[e / 2][e & 1];
-            xx = norm_unrolled_static<DP - 1>(v);
+            for (int e = 0; e < DP / 2; e += 2) v2[e / 2] = (f32x2){v[e], v[e + 1]};
         } else {
+            // VEC: all DP floats are real (dsub == DP).  Otherwise: DP <= 32 -> dsub == DP - 1 and the
+            // last one is padding; DP > 32 (wide sub-vectors, DP a multiple of 8) -> run-time dsub < DP
             float v[DP];
+            if (VEC || DP <= 32) load_row_floats<VEC ? DP : DP - 1, DP>(p, v);
+            else load_row_floats_rt<DP>(p, a.dsub, v);
 #pragma unroll
-            for (int e = 0; e < DP; ++e) v[e] = v2[e / 2][e & 1];
-            xx = norm_unrolled_padded<DP>(v, a.dsub);
+            for (int e = 0; e < DP; e += 2) v2[e / 2] = (f32x2){v[e], v[e + 1]};
         }
+    };
+    auto prep_tile = [&](const f32x2 (&v2)[NV2], float (&bop)[S], float& xx) {
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) bop[s] = h ? v2[s][1] : v2[s][0];
+            for (int i = 0; i < DP / 4; ++i) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v2[i][0]), __float_as_uint(v2[i][1]), false, false);
+                bop[i] = __uint_as_float(r[0]);             // half 0: x[2i],        half 1: x[2i + 1]
+                bop[DP / 4 + i] = __uint_as_float(r[1]);    // half 0: x[DP/2 + 2i], half 1: x[DP/2 + 2i + 1]
+            }
+            // rule 1 across the halves: half h holds the elements e = 2 s + h
+            constexpr int C = DP / 8, NT = (DP - 8 * C) / 2;
+            float sq[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) sq[s] = fmul(bop[s], bop[s]);
+            float sum = 0.f;
+            auto halves = [](float v, float& e, float& o) {
+                const unsigned u = __float_as_uint(v);
+                const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                e = __uint_as_float(r[0]);
+                o = __uint_as_float(r[1]);
+            };
+            if (C > 0) {
+                float p4[4];                                // p[l], l = 2 i + h
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    p4[i] = sq[i];                          // 0 + x == x exactly for x >= +0 or NaN
+#pragma unroll
+                    for (int c = 1; c < C; ++c) p4[i] = fadd(p4[i], sq[4 * c + i]);
+                }
+                const float u0 = fadd(p4[0], p4[2]), u1 = fadd(p4[1], p4[3]);   // half 0: p0+p4, p2+p6; half 1: p1+p5, p3+p7
+                float e0, o0, e1, o1;
+                halves(u0, e0, o0);
+                halves(u1, e1, o1);
+                sum = fadd(fadd(fadd(e0, o0), e1), o1);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                float e, o;
+                halves(sq[4 * C + i], e, o);
+                sum = fadd(fadd(sum, e), o);
+            }
+            xx = sum;
+        } else {
+            // the sub-dimension is a compile-time fact (DP or DP - 1): with a run-time test the compiler
+            // if-converts and executes BOTH norm variants for every tile (~100 VALU)
+            if (VEC) {
+                xx = norm_unrolled_packed<DP>(v2);
+            } else if (DP <= 32) {
+                float v[DP - 1];
+#pragma unroll
+                for (int e = 0; e < DP - 1; ++e) v[e] = v2[e / 2][e & 1];
+                xx = norm_unrolled_static<DP - 1>(v);
+            } else {
+                float v[DP];
+#pragma unroll
+                for (int e = 0; e < DP; ++e) v[e] = v2[e / 2][e & 1];
+                xx = norm_unrolled_padded<DP>(v, a.dsub);
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) bop[s] = h ? v2[s][1] : v2[s][0];
+        }
     };
     auto read_cc = [&](int t, f32x4 (&c)[4]) {
 #pragma unroll
@@ -121,11 +179,13 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
     }
 
     const int64_t last_tile0 = row_begin + ((row_end - row_begin - 1) / 32) * 32;
-    f32x2 vn[DP / 2];
+    f32x2 vn[NV2];
     float bop[S];
     float xx;
     load_tile(vn, row_begin);
     prep_tile(vn, bop, xx);
+    // (the row pointer only ever moves forward; once the last tile has been requested it stays there)
+    if (row_begin + 32 <= last_tile0) prow += tile_step;
     load_tile(vn, (row_begin + 32 <= last_tile0) ? row_begin + 32 : last_tile0);
 
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -135,7 +195,10 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
     f32x4 c4[4];
     read_cc(0, c4);
 
+    unsigned long long st_tiles = 0, st_steps = 0, st_seam = 0;
+    const unsigned long long st_t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
+        const unsigned long long st_a = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
         float bop_n[S];
         float xx_n = 0.f;
         const f32x2 xx2 = {xx, xx};
@@ -150,6 +213,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
                 // chain was issued one step ago): no register copies at the loop seam; the tile
                 // after next starts its trip from HBM right away
                 prep_tile(vn, bop_n, xx_n);
+                if (row0 + 64 <= last_tile0) prow += tile_step;
                 load_tile(vn, (row0 + 64 <= last_tile0) ? row0 + 64 : last_tile0);
             }
             float an[S];  // A fragments of the NEXT chain: in flight while the VALU works below
@@ -192,17 +256,22 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
             acc = nacc;
         }
 
-        float best = __builtin_inff();
-        int bidx = 0;
+        const unsigned long long st_b = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        // Fold the T per-tile slots with the LDS unit instead of the VALU: each slot is read and re-armed by one
+        // ds_wrxchg, gets its tile number OR-ed into the index bits (1 VALU), and is min-ed into slot [T]; signed
+        // 64-bit order of {bits(d), 32 t + offset} is the (distance, index) order, i.e. the first minimum over all
+        // 32 T centroids (for d >= 0; a negative minimum sorts first and sends the row to the exact path below).
+        // The chain of the next row tile is already running on the matrix core while this happens.
+        long long* fin = &slot_s[wave][T][lane];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const long long k = slot_s[wave][t][lane];
-            slot_s[wave][t][lane] = kKeyInit;
-            const float d = __int_as_float((int)(k >> 32));
-            const bool lt = d < best;
-            best = lt ? d : best;
-            bidx = lt ? ((int)(unsigned)k + 32 * t) : bidx;
+            long long k = __hip_atomic_exchange(&slot_s[wave][t][lane], kKeyInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (t > 0) k |= (long long)(32 * t);
+            (void)__hip_atomic_fetch_min(fin, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
+        const long long kf = __hip_atomic_exchange(fin, kKeyInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        float best = __int_as_float((int)(kf >> 32));
+        int bidx = (int)(unsigned)kf;
         const bool neg = best < 0.f;
         bidx += 4 * h;
         const float od = __shfl_xor(best, 32);
@@ -229,6 +298,12 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = bop_n[s];
         xx = xx_n;
+        if (a.stamps) { const unsigned long long st_c = __builtin_amdgcn_s_memtime(); st_tiles += 1; st_steps += st_b - st_a; st_seam += st_c - st_b; }
+    }
+    if (a.stamps && lane == 0) {
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 5;
+        o[0] = st_tiles; o[1] = st_steps; o[2] = st_seam;
+        o[3] = __builtin_amdgcn_s_memtime() - st_t0; o[4] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
 }
 

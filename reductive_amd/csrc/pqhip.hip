@@ -265,6 +265,16 @@ void free_staging(Staging& s)
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int32_t alloc(size_t bytes)
+    {
+        HIPCHK(hipMalloc(&p, bytes ? bytes : 1));
+        return PQHIP_OK;
+    }
+};
+
 // Lease a scratch buffer of at least `bytes` for one call on stream `st` (see ScratchBuf).  Preference:
 // an idle buffer that is large enough; an idle buffer that has to grow (or a new one while the pool is
 // below kScratchPoolMax); otherwise the call queues behind a buffer whose work is still in flight
@@ -466,7 +476,26 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         // one is padding (odd dsub).  Row alignment does not matter: the loads are dword-aligned wide loads.
         const bool vec = cb->DP == cb->dsub;
         const int grp = (cb->DP % 4 == 0) ? 4 : 2;
+        static const bool want_stamps = getenv("PQHIP_DEBUG_ENC_STAMP") != nullptr;
+        DevBuf stamp_buf;
+        const size_t n_stamp = (size_t)grid.x * 4 * 5;
+        if (want_stamps && kind == 2) {
+            PQCHK(stamp_buf.alloc(n_stamp * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(stamp_buf.p, 0, n_stamp * sizeof(unsigned long long), st));
+            a.stamps = (unsigned long long*)stamp_buf.p;
+        }
         if (!launch_encode_mfma(kind, cb->T, cb->DP, vec, code_bytes, a, grid, st)) return PQHIP_EUNSUPPORTED;
+        if (a.stamps) {   // diagnostics: synchronous summary on stderr
+            std::vector<unsigned long long> h(n_stamp);
+            HIPCHK(hipMemcpyAsync(h.data(), stamp_buf.p, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            double tiles = 0, sc = 0, ec = 0, cyc = 0, rt = 0; size_t waves = 0;
+            for (size_t i = 0; i < n_stamp; i += 5)
+                if (h[i]) { tiles += (double)h[i]; sc += (double)h[i + 1]; ec += (double)h[i + 2]; cyc += (double)h[i + 3]; rt += (double)h[i + 4]; ++waves; }
+            if (tiles > 0)
+                fprintf(stderr, "[pqhip] encode stamps: %zu waves, %.1f tiles/wave, steps %.0f cyc/tile, seam %.0f cyc/tile, wave life %.0f cyc, clock %.0f MHz\n",
+                        waves, tiles / waves, sc / tiles, ec / tiles, cyc / waves, rt > 0 ? cyc / rt * 100.0 : 0.0);
+        }
         static const char* const names[3][3] = {{"k_encode_mfma<odd>", "k_encode_mfma<vec2>", "k_encode_mfma<vec4>"},
                                                 {"", "", ""},
                                                 {"k_encode_mfma_lds3<odd>", "k_encode_mfma_lds3<vec2>", "k_encode_mfma_lds3<vec4>"}};
@@ -491,15 +520,6 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     return PQHIP_OK;
 }
 
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int32_t alloc(size_t bytes)
-    {
-        HIPCHK(hipMalloc(&p, bytes ? bytes : 1));
-        return PQHIP_OK;
-    }
-};
 
 // out[n][d] = x[n][d] . Pm   on the device
 int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, int d, float* d_out,
