@@ -5,7 +5,7 @@
 // per-distance epilogue on 32-centroid tiles; measured round 1: 2.1e9 vectors/s at that shape = 15 %
 // of HBM and 5 % of the MFMA peak -- on neither roofline.  This kernel streams x once:
 //   * one LANE owns one row (64 rows per wave); all M sub-vectors of the row are encoded by that lane,
-//     so x is read exactly once, two sub-vectors ahead of its use;
+//     so x is read exactly once -- in whole row segments staged through a wave-private LDS slab;
 //   * the centroids never touch a vector register or LDS: the transposed image cbt[m][k][KP]
 //     (k_build_cbt, kernels_basic.hip.h) is read through the SCALAR cache and a pair of centroids is the scalar operand of
 //     one v_pk_fma_f32:  (dp_j, dp_j+1) = fma(x_k, (c_j[k], c_j+1[k]), (dp_j, dp_j+1)),  k ascending
@@ -41,31 +41,60 @@ __global__ __launch_bounds__(256) void k_encode_smallk(SmallKArgs a)
 {
     static_assert(KP == 16 || KP == 32 || KP == 64, "padded centroid count");
     constexpr int JB = KP < 32 ? KP : 32;            // centroids per pass (JB / 2 accumulator pairs)
-    // x is fetched one sub-vector (DSUB floats per lane) at a time, two sub-vectors ahead of its use (three
-    // register sets).  Few registers per wave is the point: the scalar-cache round trips of the centroid
-    // blocks (~200 cycles per 8 packed fmas) are hidden by occupancy -- 6 to 8 waves per SIMD -- rather than
-    // by a deeper software pipeline, which would need ~100 SGPRs.
-    constexpr int G = 1;
-    constexpr int CF = G * DSUB;
+    // x reaches the lanes through a wave-private LDS slab: the wave fetches [64 rows][CF floats] chunks with
+    // 16-byte loads in which consecutive lanes cover consecutive bytes of a row (full 64..160-byte row
+    // segments; one row per lane straight from global memory -- 64 different cache lines per load
+    // instruction -- tops out near 3 TB/s whatever the kernel), stores them with a padded row stride and
+    // every lane reads back its own row.  A chunk is G whole sub-vectors, about 128 bytes per row; the next
+    // chunk travels from HBM into registers while the current one is encoded.
+    constexpr int G = (DSUB % 4 == 0) ? ((32 / DSUB) > 0 ? 32 / DSUB : 1) : ((DSUB % 4 == 2) ? ((32 / DSUB) / 2 * 2 > 0 ? (32 / DSUB) / 2 * 2 : 2) : 4);
+    constexpr int CF = G * DSUB;                     // floats per row and chunk: a multiple of 4
+    static_assert(CF % 4 == 0, "whole 16-byte pieces");
+    constexpr int PPR = CF / 4;                      // 16-byte pieces per row
+    constexpr int XS = CF + 4;                       // slab row stride in floats (16-byte aligned, spreads the banks)
+    __shared__ __attribute__((aligned(16))) float slab_s[4][64 * XS];
     const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;   // the wave's 64 rows
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 64;   // the wave's 64 rows
     if (row0 >= a.n) return;
     const int64_t row = row0 + lane;
     const bool valid = row < a.n;
-    const float* xr = a.x + (valid ? row : a.n - 1) * a.x_rs;   // clamped: loads stay in bounds, result not stored
     uint8_t* orow = a.out + row * a.o_rs;
+    float* slab = slab_s[wave];
+    const int nrows = (int)((a.n - row0 < 64) ? a.n - row0 : 64);
 
-    auto load_chunk = [&](float (&v)[CF], int m0) {
+    // piece p = lane + 64 i of a chunk: row p / PPR, 16-byte piece p % PPR (compile-time divisor)
+    f32x4 st[PPR];
+    auto fetch = [&](int m0) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float w[DSUB];
-            if (m0 + g < a.M) load_row_floats<DSUB, DSUB>(xr + (int64_t)(m0 + g) * DSUB, w);
-            else {
+        for (int i = 0; i < PPR; ++i) {
+            const int p = lane + 64 * i;
+            const int r = p / PPR, c = p - r * PPR;
+            const int rr = (r < nrows) ? r : nrows - 1;          // clamped: stays in bounds, result not stored
+            const int mlast = m0 + (4 * c + 3) / DSUB;           // last sub-vector this piece touches
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (mlast < a.M) v = *reinterpret_cast<const f32x4_u*>(a.x + (row0 + rr) * a.x_rs + (int64_t)m0 * DSUB + 4 * c);
+            else if (m0 + (4 * c) / DSUB < a.M) {                // piece straddles the end of the row (CF not dividing d)
 #pragma unroll
-                for (int e = 0; e < DSUB; ++e) w[e] = 0.f;
+                for (int e = 0; e < 4; ++e)
+                    if (m0 + (4 * c + e) / DSUB < a.M) v[e] = a.x[(row0 + rr) * a.x_rs + (int64_t)m0 * DSUB + 4 * c + e];
             }
+            st[i] = v;
+        }
+    };
+    auto stash = [&]() {
 #pragma unroll
-            for (int e = 0; e < DSUB; ++e) v[g * DSUB + e] = w[e];
+        for (int i = 0; i < PPR; ++i) {
+            const int p = lane + 64 * i;
+            const int r = p / PPR, c = p - r * PPR;
+            *reinterpret_cast<f32x4*>(slab + r * XS + 4 * c) = st[i];
+        }
+    };
+    auto read_row = [&](float (&v)[CF]) {
+#pragma unroll
+        for (int c = 0; c < PPR; ++c) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(slab + lane * XS + 4 * c);
+            v[4 * c] = q[0]; v[4 * c + 1] = q[1]; v[4 * c + 2] = q[2]; v[4 * c + 3] = q[3];
         }
     };
     auto encode_chunk = [&](const float (&v)[CF], int m0) {
@@ -89,7 +118,7 @@ __global__ __launch_bounds__(256) void k_encode_smallk(SmallKArgs a)
                     for (int i = 0; i < JB / 2; ++i) acc[i] = (f32x2){0.f, 0.f};
                     // The centroid block of step k + 1 is requested (64-byte scalar loads, s_load_dwordx16: the scalar
                     // cache is shared by every wave of the CU, so one request per 16 centroids, not one per pair)
-                    // before the packed fmas of step k are issued: a scalar-cache round trip hides behind them.
+                    // before the packed fmas of step k are issued.
                     f32x16 cur[JB / 16], nxt[JB / 16];
 #pragma unroll
                     for (int i16 = 0; i16 < JB / 16; ++i16) cur[i16] = *(sk_c16ptr)(cm + jb + 16 * i16);
@@ -146,16 +175,18 @@ __global__ __launch_bounds__(256) void k_encode_smallk(SmallKArgs a)
         }
     };
 
-    float xa[CF], xb_[CF], xc[CF];
-    load_chunk(xa, 0);
-    if (1 < a.M) load_chunk(xb_, 1);
-    for (int m0 = 0; m0 < a.M; m0 += 3) {
-        if (m0 + 2 < a.M) load_chunk(xc, m0 + 2);
-        encode_chunk(xa, m0);
-        if (m0 + 3 < a.M) load_chunk(xa, m0 + 3);
-        if (m0 + 1 < a.M) encode_chunk(xb_, m0 + 1);
-        if (m0 + 4 < a.M) load_chunk(xb_, m0 + 4);
-        if (m0 + 2 < a.M) encode_chunk(xc, m0 + 2);
+    float xv[CF];
+    fetch(0);
+    stash();
+    read_row(xv);
+    for (int m0 = 0; m0 < a.M; m0 += G) {
+        const bool more = m0 + G < a.M;
+        if (more) fetch(m0 + G);                 // next chunk: HBM -> registers while this one is encoded
+        encode_chunk(xv, m0);
+        if (more) {                              // (wave-private slab, LDS is in order per wave: no barrier)
+            stash();
+            read_row(xv);
+        }
     }
 }
 

@@ -409,11 +409,12 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     CodebookDev& cd = cb->dev[slot];
     if (cb->groups > 1 && cb->variant != 1 && cb->norms_ok && code_bytes == 4)
         return encode_grouped_dev(cb, slot, d_x, n, x_rs, d_codes, o_rs, st);
-    // Small codebooks are HBM-bound: the VALU kernel reads x once and keeps the centroids on the scalar path
-    // (kernels_smallk.hip.h).  Auto choice for K <= 16 (measured +40 % over the MFMA kernel at d = 128, M = 16,
-    // K = 16; at K = 32 / 64 the MFMA kernel is still the faster one) when the host knows the norms are finite;
-    // variant 6 forces it for any K <= 64.
-    if (((cb->variant == 0 && cb->KP == 16) || cb->variant == 6) && cb->KP != 0 && code_bytes == 1 && cb->norms_ok &&
+    // Small codebooks: the VALU kernel reads x once, in whole row segments, and keeps the centroids on the scalar
+    // path (kernels_smallk.hip.h).  Auto choice for K <= 16 with sub-vectors of <= 8 floats -- the reference's
+    // own bench shape, d = 128, M = 16, K = 16: 6.3e9 vectors/s against 4.4e9 for the MFMA kernel; for wider
+    // sub-vectors or K = 32 / 64 the MFMA kernels are still the faster ones (tools/smallk_sweep.sh) -- when the
+    // host knows the norms are finite; variant 6 forces it for any K <= 64.
+    if (((cb->variant == 0 && cb->KP == 16 && cb->dsub <= 8) || cb->variant == 6) && cb->KP != 0 && code_bytes == 1 && cb->norms_ok &&
         bad_flag == nullptr) {
         SmallKArgs a;
         a.x = d_x; a.n = n; a.x_rs = x_rs; a.out = (uint8_t*)d_codes; a.o_rs = o_rs;

@@ -31,13 +31,13 @@ def test_every_instantiation_matches_oracle(ra, K, dsub):
     x = synth.normalish(7400 + K + dsub, (n, M * dsub))
     want = orc.quantize_batch(q, x, n_threads=8)
     pq = ra.Pq(None, q)
-    pq.set_encode_variant(6)         # auto takes this kernel for K <= 16 only; 6 forces it up to K = 64
+    pq.set_encode_variant(6)         # auto takes this kernel for K <= 16, dsub <= 8 only; 6 forces it up to K = 64
     got = pq.quantize_batch_device(torch.from_numpy(x).cuda())
     assert pq.last_encode_kernel() == "k_encode_smallk"
     assert got.cpu().numpy().tobytes() == want.tobytes()
     auto = ra.Pq(None, q)
     assert auto.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy().tobytes() == want.tobytes()
-    assert (auto.last_encode_kernel() == "k_encode_smallk") == (K <= 16)
+    assert (auto.last_encode_kernel() == "k_encode_smallk") == (K <= 16 and dsub <= 8)
     pq4 = ra.Pq(None, q)
     pq4.set_encode_variant(4)        # the MFMA kernel on the same input
     got4 = pq4.quantize_batch_device(torch.from_numpy(x).cuda())
