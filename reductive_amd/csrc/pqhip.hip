@@ -55,8 +55,10 @@ thread_local std::string g_hip_err;
 
 constexpr int64_t kStageBytes = 256ll << 20;   // input bytes per pinned staging buffer of a host-resident call (two per device)
 constexpr int64_t kStageRowsMin = 4096;
-constexpr int64_t kScratchBytesMax = 2ll << 30;   // one leased scratch buffer: <= 2 GiB (larger batches are chunked)
-constexpr int kScratchPoolMax = 4;                // leased scratch buffers per (codebook, device): <= 8 GiB of the 288 GB HBM
+constexpr int64_t kScratchBytesMax = 4ll << 30;   // one leased scratch buffer: <= 4 GiB (larger batches are chunked; every chunk
+                                                  // boundary costs two kernel tails, ~0.3 ms: 10 M x 300 rows = 3 chunks)
+constexpr int kScratchPoolMax = 3;                // leased scratch buffers per (codebook, device): <= 12 GiB of the 288 GB HBM,
+                                                  // and only while that many callers are inside OPQ calls at once
 constexpr int kErrSlots = 64;                     // per-stream "code >= K" flags per (codebook, device)
 constexpr int kTrainWs = 10;                      // grow-only training workspaces per device
 
