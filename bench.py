@@ -272,6 +272,22 @@ class Bench:
                 cpu_rec = cpu_baseline_kmeans(args, q0, src, self.ctx)
             elif workload == "adc_scan":
                 cpu_rec = cpu_baseline_adc(q, query, src, dst, lut)
+        if workload in ("reconstruct", "lookup") and not args.no_cpu_baseline:
+            # what plain streaming stores reach on THIS output allocation of THIS box (torch fill_, no reads): the
+            # write rate moves 5-9 % with the physical placement of the buffer for every store pattern
+            # (tools/store_patterns.hip), so the kernel is also quoted against it.  After the parity
+            # check above, which reads the output.
+            flat = dst.view(-1)
+            parts = [flat[i:i + (1 << 30)] for i in range(0, flat.numel(), 1 << 30)]
+
+            def fill():
+                for part in parts:
+                    part.fill_(1.0)
+            _, _, fmin, _ = self.timed(fill, 3, 1)
+            ceil_gbs = flat.numel() * 4 / (fmin * 1e-3) / 1e9
+            roof["store_ceiling"] = {"gbs": ceil_gbs, "kernel_over_ceiling": 4 * d * rows / sec / 1e9 / ceil_gbs,
+                                     "what": "torch fill_ of the same output buffer, best of 3, measured after the timed region (output bytes only on both sides of the ratio)"}
+            del flat, parts
         del src, dst
         pq.close()
         torch.cuda.empty_cache()

@@ -166,6 +166,7 @@ private:
 
 struct DeviceSlot {
     int ordinal = -1;
+    int n_cus = 256;                 // compute units of the device (grid sizing of the persistent kernels)
     std::unique_ptr<RowPool> pool;   // created with the context
     std::mutex mu;  // serialises host-resident calls and scratch (re)allocation on this device
     hipStream_t stream[2] = {nullptr, nullptr};
@@ -998,6 +999,30 @@ int32_t atb_dev(DeviceSlot& ds, const float* dA, int64_t a_rs, int da, const flo
     return PQHIP_OK;
 }
 
+// Workgroups of 256 threads of `kernel` that one CU holds at once with `lds` bytes of dynamic LDS (occupancy
+// API; cached per thread for the last few (kernel, lds) pairs -- the query is a host-side table walk, but the
+// small-batch path should not pay it per call).
+int resident_wgs(const void* kernel, size_t lds)
+{
+    struct Ent { const void* k; size_t lds; int dev; int n; };
+    thread_local Ent cache[8] = {};
+    thread_local int next = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (const Ent& e : cache)
+        if (e.k == kernel && e.lds == lds && e.dev == dev) return e.n;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, lds) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 4;
+    }
+    cache[next] = Ent{kernel, lds, dev, nb};
+    next = (next + 1) % 8;
+    return nb;
+}
+
+int cus_of(pqhip_codebook* cb, int slot) { return cb->ctx->devs[slot]->n_cus; }
+
 int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes, int64_t n,
                    int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st, int* err,
                    const int64_t* sel_rows = nullptr, int64_t n_codes = 0, const float* sel_scales = nullptr)
@@ -1032,14 +1057,23 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
         HIPCHK(hipGetLastError());
         return PQHIP_OK;
     }
-    static const int rec_wgs_per_cu = [] { const char* e = getenv("PQHIP_DEBUG_REC_WGS"); return e ? std::max(1, atoi(e)) : 8; }();
-    const unsigned grid =
-        (unsigned)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, (int64_t)256 * rec_wgs_per_cu);
+    // grid = the workgroups that are RESIDENT at once (occupancy API x CUs), each owning one contiguous range of
+    // row blocks.  Round 1 launched 8 per CU although the kernel's registers allow 4: the second half of the
+    // ranges then ran as a second round behind the first, and the 100 M-row launch took 18.7 or 21.0 ms depending
+    // on which allocation the output was (tools/rec_variance*.py).  The lookup form (random source
+    // rows: workgroup times vary) takes whole multiples of its resident count, three rounds of shorter ranges.
+    // PQHIP_DEBUG_REC_WGS overrides the per-CU count.
+    static const int rec_wgs_per_cu = [] { const char* e = getenv("PQHIP_DEBUG_REC_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
+    const int64_t nblocks = (n + rows_per_block - 1) / rows_per_block;
     const size_t lds = (((size_t)cpr * (vec ? 4 / gsz : 1) * sizeof(int) + 15) & ~(size_t)15) +
                        (((size_t)2 * rows_per_block * cb->M * code_bytes + 15) & ~(size_t)15) +
                        (sel_rows ? (size_t)2 * rows_per_block * sizeof(float) : 0);
 #define LAUNCH_REC2(IDX, V, GG)                                                                   \
     do {                                                                                          \
+        const int per_cu = rec_wgs_per_cu ? rec_wgs_per_cu                                        \
+            : sel_rows ? 3 * resident_wgs((const void*)k_reconstruct<IDX, V, true, GG>, lds)      \
+                       : resident_wgs((const void*)k_reconstruct<IDX, V, false, GG>, lds);        \
+        const unsigned grid = (unsigned)std::min<int64_t>(nblocks, (int64_t)cus_of(cb, slot) * per_cu); \
         if (sel_rows)                                                                             \
             hipLaunchKernelGGL((k_reconstruct<IDX, V, true, GG>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
@@ -1306,6 +1340,7 @@ int32_t pqhip_ctx_create(const int32_t* devices, int32_t n_devices, pqhip_ctx** 
         }
         std::unique_ptr<DeviceSlot> ds(new DeviceSlot());
         ds->ordinal = o;
+        if (prop.multiProcessorCount > 0) ds->n_cus = prop.multiProcessorCount;
         SET_DEVICE(o);
         HIPCHK(hipStreamCreateWithFlags(&ds->stream[0], hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&ds->stream[1], hipStreamNonBlocking));

@@ -30,6 +30,25 @@ def counter(d, name, kernel):
                 vals.append(float(r["Counter_Value"]))
     return vals
 
+def all_kernels(d):
+    """name -> (calls, average ns) of every pqhip kernel of the stats pass"""
+    out = {}
+    for p in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+        for r in csv.DictReader(open(p)):
+            if "pqhip::" in r["Name"]:
+                out[r["Name"]] = (int(r["Calls"]), float(r["AverageNs"]))
+    return out
+
+def step_total(d, name, kernels, n_steps):
+    """sum of a counter over every dispatch of the per-step kernels, per bench step (warm-up steps run the same
+    launches, so the pass total divides by warm-up + timed steps)"""
+    tot = 0.0
+    for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(p)):
+            if r["Counter_Name"] == name and r["Kernel_Name"] in kernels:
+                tot += float(r["Counter_Value"])
+    return tot / n_steps
+
 out_dir, wls = sys.argv[1], sys.argv[2:]
 entries = {}
 for w in wls:
@@ -59,5 +78,19 @@ for w in wls:
                     "fetch_bytes": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
                     "algorithmic_bytes": alg, "ratio": (fetch_b + write_b) / alg if alg else None,
                     "dispatches_averaged": len(f), "source_hash": bench.source_hash()}
+    # a step that is several launches (rotation + encode per chunk): the record a bench line needs is the whole
+    # step's traffic, so sum every kernel that runs a whole number of times per step
+    n_steps = b["steps"] + b["warmup"]
+    ks = {k: v for k, v in all_kernels(os.path.join(out_dir, w, "stats")).items() if v[0] >= n_steps and v[0] % n_steps == 0}
+    if len(ks) > 1 or int(s["Calls"]) != n_steps:
+        sf = step_total(os.path.join(out_dir, w, "fetch"), "FETCH_SIZE", ks, n_steps) * 1024 * 2
+        sw = step_total(os.path.join(out_dir, w, "write"), "WRITE_SIZE", ks, n_steps) * 1024
+        e = entries[key]
+        e["dominant_kernel_bytes_per_launch"] = e["hbm_bytes_per_launch"]
+        e["launches_per_step"] = {k[:80]: v[0] // n_steps for k, v in ks.items()}
+        e["kernel_ms_per_step"] = sum(v[0] // n_steps * v[1] for v in ks.values()) / 1e6
+        e["fetch_bytes"], e["write_bytes"], e["hbm_bytes_per_launch"] = sf, sw, sf + sw
+        e["ratio"] = (sf + sw) / alg if alg else None
+        e["note"] = "one bench step = several launches; bytes are the sum over all of them"
 print(json.dumps({"_comment": "HBM bytes per launch of each workload's dominant kernel from rocprofv3 --pmc passes (tools/pmc_collect.sh; FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE x1024 x2 per the gfx950 correction in MI355X_MICROARCH.md 'HBM', WRITE_SIZE x1024). bench.py reports an entry only when workload, size and source_hash match the build it runs.",
                   "entries": entries}, indent=1))
