@@ -40,6 +40,7 @@ WORKLOADS = {
     "encode": ("Pq::quantize_batch {rows} x d={d} fp32 per GPU, M={m}, K={k} (BASELINE configs[1]: 10M on 1 MI355X)", (300, 15, 256), 10_000_000),
     "opq_encode": ("Opq rotate+encode {rows} x d={d} per GPU, M={m}, K={k} (BASELINE configs[2])", (300, 15, 256), 10_000_000),
     "reconstruct": ("Pq::reconstruct_batch {rows} u8 codes -> d={d} fp32 per GPU (BASELINE configs[3]: 100M codes on 1 MI355X)", (300, 15, 256), 10_000_000),
+    "opq_reconstruct": ("Opq reconstruct_batch {rows} u8 codes -> gather -> x P^T -> d={d} fp32 per GPU (SURVEY 8a row a8 with a projection)", (300, 15, 256), 10_000_000),
     "encode_d768": ("Pq encode {rows} x d={d} per GPU, M={m}, K={k}: one GPU's shard of BASELINE configs[4] (100M x d=768, M=48 batch-sharded across 8 MI355X = 12.5M rows per GPU)", (768, 48, 256), 12_500_000),
     "lookup": ("embedding lookup: {rows} random rows of a resident 10M x {m} u8 code matrix -> select + reconstruct + per-row rescale, d={d} fp32 (SURVEY 8f rank 2)", (300, 15, 256), 10_000_000),
     "adc_scan": ("asymmetric-distance scan: {rows} resident u8 code rows (M={m}) against the K={k}-entry lookup tables of one query, d={d} (SURVEY 8f rank 4)", (300, 15, 256), 100_000_000),
@@ -161,18 +162,18 @@ class Bench:
         flop_enc = 2 * k * d                      # distance GEMM only
         bytes_vec = 4 * d + m                     # algorithmic HBM bytes per vector
         q = synth.normalish(43, (m, k, dsub))     # same codebook on every rank (replicated)
-        P = synth.orthonormal(44, d) if workload == "opq_encode" else None
+        P = synth.orthonormal(44, d) if workload in ("opq_encode", "opq_reconstruct") else None
         pq = self.ra.Pq(P, q, ctx=self.ctx)
         if args.variant:
             pq.set_encode_variant(args.variant)
         g = torch.Generator(device=self.dev).manual_seed(42 + self.rank)
         extra, cpu_rec, q0 = {}, None, None
         kernel = None
-        if workload == "reconstruct":
+        if workload in ("reconstruct", "opq_reconstruct"):
             src = torch.randint(0, k, (rows, m), device=self.dev, dtype=torch.uint8, generator=g)
             dst = torch.empty((rows, d), device=self.dev, dtype=torch.float32)
             step = lambda: pq.reconstruct_batch_device(src, out=dst, check=False)
-            kernel = "k_reconstruct"
+            kernel = "k_reconstruct" if workload == "reconstruct" else "k_reconstruct + k_rotate_pblock6 (x P^T)"
         elif workload == "lookup":
             n_codes = 10_000_000
             src = torch.randint(0, k, (n_codes, m), device=self.dev, dtype=torch.uint8, generator=g)
@@ -228,7 +229,7 @@ class Bench:
         if kernel is None:
             kernel = pq.last_encode_kernel() if workload != "kmeans" else None
         if kernel:
-            extra["encode_kernel" if workload not in ("reconstruct", "lookup", "adc_scan") else "kernel"] = kernel
+            extra["encode_kernel" if workload not in ("reconstruct", "opq_reconstruct", "lookup", "adc_scan") else "kernel"] = kernel
 
         sec = kernel_ms * 1e-3
         traffic_rec, why = load_pmc_traffic(workload, rows, d, m, k)
@@ -247,11 +248,13 @@ class Bench:
             flop = flop_enc + (2 * d * d if workload == "opq_encode" else 0)
             if workload == "opq_train":           # rotation + 2 assignments + cross product
                 flop = 2 * d * d + 2 * flop_enc + 2 * d * d
+            if workload == "opq_reconstruct":     # the inverse rotation only (+ 2 d^2 per vector)
+                flop = 2 * d * d
             ach = flop * rows / sec / 1e12
             ek = kernel or "k_encode_mfma_lds3"
             roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                    "kernel": {"encode": ek, "encode_d768": ek, "opq_encode": ("k_opq_encode_fused (rotation + encode in one kernel)" if ek == "k_opq_encode_fused" else "k_rotate_pblock6 + " + ek),
+                    "kernel": {"encode": ek, "encode_d768": ek, "opq_reconstruct": ek, "opq_encode": ("k_opq_encode_fused (rotation + encode in one kernel)" if ek == "k_opq_encode_fused" else "k_rotate_pblock6 + " + ek),
                                "kmeans": "encode kernel + k_km_{hist,scan,scatter,segsum} + codebook prep (whole iteration)",
                                "opq_train": "k_rotate_pblock6 + 2 x " + ek + " + k_km_* + k_reconstruct + k_atb_blocks/fold (whole step)"}[workload],
                     "avg_launch_ms": kernel_ms, "min_launch_ms": kmin, "max_launch_ms": kmax,
@@ -268,6 +271,8 @@ class Bench:
                 cpu_rec = cpu_baseline(args, q, P, src, dst, pq, full=(workload == "encode"))
             elif workload == "reconstruct":
                 cpu_rec = cpu_baseline_reconstruct(q, src, dst)
+            elif workload == "opq_reconstruct":
+                cpu_rec = cpu_baseline_reconstruct(q, src, dst, P)
             elif workload == "kmeans":
                 cpu_rec = cpu_baseline_kmeans(args, q0, src, self.ctx)
             elif workload == "adc_scan":
@@ -297,6 +302,7 @@ class Bench:
 
 METRIC_NAMES = {"encode": "vectors/sec PQ encode", "encode_d768": "vectors/sec PQ encode",
                 "opq_encode": "vectors/sec OPQ rotate+encode", "reconstruct": "vectors/sec PQ reconstruct",
+                "opq_reconstruct": "vectors/sec OPQ reconstruct (gather + inverse rotation)",
                 "lookup": "vectors/sec select+reconstruct+rescale lookup",
                 "adc_scan": "codes/sec asymmetric-distance scan",
                 "opq_train": "vectors/sec per OPQ training iteration (device part)",
@@ -506,27 +512,41 @@ def cpu_baseline(args, q, P, src, dst, pq, full=True):
     return rec
 
 
-def cpu_baseline_reconstruct(q, src, dst):
+def cpu_baseline_reconstruct(q, src, dst, P=None):
     """BASELINE.md B-rec: the oracle's gather (primitives.rs:110-173 semantics, single thread as in the
     reference) on head, middle and TAIL row ranges of the launch -- for the 100 M-code config the tail
     rows sit beyond element offset 2^32 of the output and beyond the Infinity Cache's reach of the code
-    matrix -- and the GPU rows checked against it byte for byte."""
+    matrix -- and the GPU rows checked against it byte for byte.  With a projection (pq.rs:323-326) the
+    oracle also un-rotates, and the comparison is SURVEY.md 8c rule 6: 1e-5 of the largest magnitude."""
+    import numpy as np
     from oracle import pq_oracle as orc
     rows = src.shape[0]
-    n_s = min(250_000, rows)
+    n_s = min(250_000 if P is None else 50_000, rows)
     starts = sorted({0, max(0, rows // 2 - n_s // 2), max(0, rows - n_s)})
-    t_cpu, ok, n_tot = 0.0, True, 0
+    t_cpu, ok, n_tot, worst = 0.0, True, 0, 0.0
     for s0 in starts:
         c_host = src[s0:s0 + n_s].cpu().numpy()
         t = time.perf_counter()
-        want = orc.reconstruct_batch(q, c_host)
+        want = orc.reconstruct_batch(q, c_host) if P is None else orc.reconstruct_batch(q, c_host, projection=P)
         t_cpu += time.perf_counter() - t
         n_tot += c_host.shape[0]
-        ok = ok and bool(dst[s0:s0 + n_s].cpu().numpy().tobytes() == want.tobytes())
-    return {"value": n_tot / t_cpu, "unit": "vectors/s", "cores": 1, "kind": "port",
-            "sample": "%d code rows at row offsets %s of the bench batch (head, middle, tail; last output element offset %d), "
-                      "oracle gather on one thread (%.1f s)" % (n_s, starts, rows * q.shape[0] * q.shape[2] - 1, t_cpu),
-            "gpu_rows_identical_on_sample": ok}
+        got = dst[s0:s0 + n_s].cpu().numpy()
+        if P is None:
+            ok = ok and bool(got.tobytes() == want.tobytes())
+        else:
+            rel = float(np.abs(got - want).max() / np.abs(want).max())
+            worst = max(worst, rel)
+            ok = ok and rel <= 1e-5
+    rec = {"value": n_tot / t_cpu, "unit": "vectors/s", "cores": 1, "kind": "port",
+           "sample": "%d code rows at row offsets %s of the bench batch (head, middle, tail; last output element offset %d), "
+                     "oracle %s on one thread (%.1f s)" % (n_s, starts, rows * q.shape[0] * q.shape[2] - 1,
+                                                           "gather" if P is None else "gather + inverse rotation", t_cpu)}
+    if P is None:
+        rec["gpu_rows_identical_on_sample"] = ok
+    else:
+        rec["gpu_rows_within_1e-5_on_sample"] = ok
+        rec["max_rel_error"] = worst
+    return rec
 
 
 def cpu_baseline_kmeans(args, q0, src, ctx):

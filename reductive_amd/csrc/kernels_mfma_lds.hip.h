@@ -18,6 +18,10 @@
 #pragma once
 #include "kernels_mfma.hip.h"
 
+#ifndef ENC_ABLATE
+#define ENC_ABLATE 0      // timing experiments only (results are wrong): 1 no fold/store, 2 no keys/atomics/fold, 3 no atomics, 4 no x loads
+#endif
+
 namespace pqhip {
 
 // ---------------------------------------------------------------------------------------------
@@ -195,6 +199,48 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
     f32x4 c4[4];
     read_cc(0, c4);
 
+    // ---- end of a row tile.  The T per-tile slots are folded by the LDS unit, not the VALU: each slot is read, gets
+    // its tile number OR-ed into the index bits (1 VALU) and goes into slot [T] -- the first one by a plain store, the
+    // others by ds_min -- and the final key is read back.  Signed 64-bit order of {bits(d), 32 t + offset} is the
+    // (distance, index) order, i.e. the first minimum over all 32 T centroids (for d >= 0; a negative minimum sorts
+    // first and sends the row to the exact path).  Nothing is ever re-armed: the first key of every step and of every
+    // fold is a store.  (Round 2 measured the LDS unit, not the VALU, as this kernel's busiest resource: without the
+    // 128 atomics per row tile it runs 10 % faster, without the fold 6 %.  Moving the fold into the next tile's steps
+    // -- one slot per step -- removed the 3.7 k-cycle seam and 5 % of the cycles per tile, and the GPU answered with a
+    // 2 % lower clock under its power cap: no gain in ms, so the simple form stays.)
+    long long* const fin = &slot_s[wave][T][lane];
+    auto finish_tile = [&](long long kf, int64_t trow0, int big) {
+        float best = __int_as_float((int)(kf >> 32));
+        int bidx = (int)(unsigned)kf;
+        const bool neg = best < 0.f;
+        bidx += 4 * h;
+        // the other half's candidate through v_permlane32_swap (VALU) instead of two ds_bpermute round trips:
+        // the LDS unit is this kernel's busiest resource (128 atomics + 80 fragment reads per row tile and wave)
+        // (swap(u, u): [0] = the lower half's value, [1] = the upper half's value, in every lane)
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)bidx, (unsigned)bidx, false, false);
+        const float od = __uint_as_float(h ? s0[0] : s0[1]);
+        const int oi = (int)(h ? s1[0] : s1[1]);
+        if (od < best || (od == best && oi < bidx)) bidx = oi;
+        const int64_t row = trow0 + j;
+        const bool valid = row < a.n;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && (big != 0 || neg));
+        const unsigned need = (unsigned)(bal | (bal >> 32));  // rows of this tile that need the exact path
+        if (h == 0 && valid && !((need >> j) & 1u)) {
+            if (KEYS) {
+                const float bd = (od < best) ? od : best;   // finite and >= 0 here
+                const unsigned gidx = (unsigned)bidx + 256u * (unsigned)(m - m_real * a.groups);
+                reinterpret_cast<unsigned long long*>(a.out)[row * a.o_rs + m] =
+                    ((unsigned long long)ord_key(bd) << 32) | (unsigned long long)gidx;
+            } else {
+                reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
+            }
+        }
+        if (need)
+            encode_rows_slow_v<IdxT>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad,
+                                     KEYS ? a.groups : 0, m, trow0, need);
+    };
+
     unsigned long long st_tiles = 0, st_steps = 0, st_seam = 0;
     const unsigned long long st_t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
@@ -214,7 +260,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
                 // after next starts its trip from HBM right away
                 prep_tile(vn, bop_n, xx_n);
                 if (row0 + 64 <= last_tile0) prow += tile_step;
-                load_tile(vn, (row0 + 64 <= last_tile0) ? row0 + 64 : last_tile0);
+                if (ENC_ABLATE != 4) load_tile(vn, (row0 + 64 <= last_tile0) ? row0 + 64 : last_tile0);
             }
             float an[S];  // A fragments of the NEXT chain: in flight while the VALU works below
 #pragma unroll
@@ -223,7 +269,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
             // ---- VALU: 16 distances -> 16 keys ----
             long long key[16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < 4 && ENC_ABLATE != 2; ++g) {
                 const f32x2 c01 = {c4[g][0], c4[g][1]}, c23 = {c4[g][2], c4[g][3]};
                 f32x2 t01, t23;
                 asm("v_pk_add_f32 %0, %1, %2" : "=v"(t01) : "v"(xx2), "v"(c01));
@@ -247,9 +293,15 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
                 nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(an[s], (t + 1 < T) ? bop[s] : bop_n[s],
                                                            nacc, 0, 0, 0);
 #pragma unroll
-                for (int r = (16 * s) / S; r < (16 * (s + 1)) / S; ++r)
-                    (void)__hip_atomic_fetch_min(slot, key[r], __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+                for (int r = (16 * s) / S; r < (16 * (s + 1)) / S; ++r) {
+                    if (ENC_ABLATE == 2) continue;
+                    if (ENC_ABLATE == 3) { asm volatile("" ::"v"(key[r])); continue; }
+                    // the step's first key is stored (a ds_write instead of a read-modify-write, and the slot needs
+                    // no re-arming after the previous row tile), the other 15 are min-ed into it
+                    if (r == 0) __hip_atomic_store(slot, key[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    else (void)__hip_atomic_fetch_min(slot, key[r], __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
             }
             read_cc((t + 1) % T, c4);
             __builtin_amdgcn_sched_barrier(0);
@@ -257,44 +309,23 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
         }
 
         const unsigned long long st_b = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
-        // Fold the T per-tile slots with the LDS unit instead of the VALU: each slot is read and re-armed by one
-        // ds_wrxchg, gets its tile number OR-ed into the index bits (1 VALU), and is min-ed into slot [T]; signed
-        // 64-bit order of {bits(d), 32 t + offset} is the (distance, index) order, i.e. the first minimum over all
-        // 32 T centroids (for d >= 0; a negative minimum sorts first and sends the row to the exact path below).
-        // The chain of the next row tile is already running on the matrix core while this happens.
-        long long* fin = &slot_s[wave][T][lane];
+        // fold + code byte (see finish_tile above); the chain of the next row tile is already on the matrix core
+        if (ENC_ABLATE == 1 || ENC_ABLATE == 2) {
+            asm volatile("" ::"v"(acc));
+#pragma unroll
+            for (int s = 0; s < S; ++s) bop[s] = bop_n[s];
+            xx = xx_n;
+            continue;
+        }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            long long k = __hip_atomic_exchange(&slot_s[wave][t][lane], kKeyInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            long long k = __hip_atomic_load(&slot_s[wave][t][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             if (t > 0) k |= (long long)(32 * t);
-            (void)__hip_atomic_fetch_min(fin, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (t == 0) __hip_atomic_store(fin, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            else (void)__hip_atomic_fetch_min(fin, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
-        const long long kf = __hip_atomic_exchange(fin, kKeyInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        float best = __int_as_float((int)(kf >> 32));
-        int bidx = (int)(unsigned)kf;
-        const bool neg = best < 0.f;
-        bidx += 4 * h;
-        const float od = __shfl_xor(best, 32);
-        const int oi = __shfl_xor(bidx, 32);
-        if (od < best || (od == best && oi < bidx)) bidx = oi;
-
-        const int64_t row = row0 + j;
-        const bool valid = row < a.n;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && (bad_codebook || !(xx < kBigNorm) || neg));
-        const unsigned need = (unsigned)(bal | (bal >> 32));  // rows of this tile that need the exact path
-        if (h == 0 && valid && !((need >> j) & 1u)) {
-            if (KEYS) {
-                const float bd = (od < best) ? od : best;   // finite and >= 0 here
-                const unsigned gidx = (unsigned)bidx + 256u * (unsigned)(m - m_real * a.groups);
-                reinterpret_cast<unsigned long long*>(a.out)[row * a.o_rs + m] =
-                    ((unsigned long long)ord_key(bd) << 32) | (unsigned long long)gidx;
-            } else {
-                reinterpret_cast<IdxT*>(a.out)[row * a.o_rs + m] = (IdxT)bidx;
-            }
-        }
-        if (need)
-            encode_rows_slow_v<IdxT>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad,
-                                     KEYS ? a.groups : 0, m, row0, need);
+        finish_tile(__hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT), row0,
+                    (bad_codebook || !(xx < kBigNorm)) ? 1 : 0);
 #pragma unroll
         for (int s = 0; s < S; ++s) bop[s] = bop_n[s];
         xx = xx_n;

@@ -1262,13 +1262,20 @@ uint64_t load_code(const void* base, int bytes, int64_t off)
 
 template <int NV>
 int32_t launch_adc_nv(int nv, const uint8_t* codes, int64_t n, int64_t c_rs, const float* lut, int M, int K, float* out,
-                      int64_t rows_per_wg, unsigned grid, size_t lds, int* err, hipStream_t st)
+                      int n_cus, size_t lds, int* err, hipStream_t st)
 {
     if constexpr (NV > kAdcMaxValueWords) {
         return PQHIP_EUNSUPPORTED;
     } else {
-        if (nv != NV) return launch_adc_nv<NV + 1>(nv, codes, n, c_rs, lut, M, K, out, rows_per_wg, grid, lds, err, st);
+        if (nv != NV) return launch_adc_nv<NV + 1>(nv, codes, n, c_rs, lut, M, K, out, n_cus, lds, err, st);
         HIPCHK(hipFuncSetAttribute((const void*)k_adc_scan_u8<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        // all workgroups resident at once (occupancy API: registers and the LDS table both count), one contiguous
+        // row range each -- the table is loaded once per workgroup
+        static const int adc_wgs = [] { const char* e = getenv("PQHIP_DEBUG_ADC_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
+        const int64_t max_wgs = (int64_t)n_cus * (adc_wgs ? adc_wgs : resident_wgs((const void*)k_adc_scan_u8<NV>, lds));
+        int64_t rows_per_wg = round_up((n + max_wgs - 1) / max_wgs, 256);
+        rows_per_wg = std::max<int64_t>(rows_per_wg, 1024);
+        const unsigned grid = (unsigned)((n + rows_per_wg - 1) / rows_per_wg);
         hipLaunchKernelGGL((k_adc_scan_u8<NV>), dim3(grid), dim3(256), lds, st, codes, n, c_rs, lut, M, K, out, rows_per_wg, err);
         return PQHIP_OK;
     }
@@ -1512,13 +1519,7 @@ int32_t pqhip_adc_scan_f32_dev(pqhip_codebook* cb, int32_t slot, const float* d_
         const float* lut = d_tables + q * (int64_t)M * K;
         float* out = d_out + q * o_rs;
         if (fast) {
-            // all workgroups resident at once, one contiguous row range each (the table is loaded once per workgroup)
-            const int wgs_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-            const int64_t max_wgs = (int64_t)256 * wgs_per_cu;
-            int64_t rows_per_wg = round_up((n + max_wgs - 1) / max_wgs, 256);
-            rows_per_wg = std::max<int64_t>(rows_per_wg, 1024);
-            const unsigned grid = (unsigned)((n + rows_per_wg - 1) / rows_per_wg);
-            PQCHK(launch_adc_nv<1>(nv, (const uint8_t*)d_codes, n, c_rs, lut, M, K, out, rows_per_wg, grid, lds, err, st));
+            PQCHK(launch_adc_nv<1>(nv, (const uint8_t*)d_codes, n, c_rs, lut, M, K, out, cb->ctx->devs[slot]->n_cus, lds, err, st));
         } else {
             const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 32);
             if (code_bytes == 1)
