@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_merge_keys(const unsigned long long* __
 // G = floats fetched per codebook access inside a 16-byte output chunk: 4 when sub-vectors are made
 // of 16-byte groups, 2 or 1 when a chunk spans several sub-vectors (dsub = 2, 6, 10, .. / odd dsub);
 // the store is one dword-aligned 16-byte store either way.
-template <typename IdxT, int VEC, bool SEL = false, int G = VEC>
+template <typename IdxT, int VEC, bool SEL = false, int G = VEC, int NE = 16>
 __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ codes, int64_t n,
                                                      int64_t c_rs, float* __restrict__ out,
                                                      int64_t o_rs, const float* __restrict__ cb,
@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
     // store); fetching them one whole block ahead into LDS takes that round trip off the chain
     // (measured: without it the kernel drops from 5.3 to 3.8 TB/s as soon as the code matrix no
     // longer fits the 256 MB Infinity Cache, i.e. beyond ~17 M rows at M = 15).
-    constexpr int NE = 16;  // code elements per thread per block (rows_per_block * M <= 256 * NE)
+    // NE = code elements a thread prefetches per block (rows_per_block * M <= 256 * NE): 16 in general, 4 when the
+    // block's codes fit 1024 elements (M <= 16 at 64 rows per block) -- 12 registers less, which is what lets a
+    // fourth (lookup form) / fifth workgroup live on a CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int d = M * dsub;
     const int cpr = d / VEC;  // chunks per row

@@ -1060,30 +1060,38 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     // grid = the workgroups that are RESIDENT at once (occupancy API x CUs), each owning one contiguous range of
     // row blocks.  Round 1 launched 8 per CU although the kernel's registers allow 4: the second half of the
     // ranges then ran as a second round behind the first, and the 100 M-row launch took 18.7 or 21.0 ms depending
-    // on which allocation the output was (tools/rec_variance*.py).  The lookup form (random source
-    // rows: workgroup times vary) takes whole multiples of its resident count, three rounds of shorter ranges.
+    // on which allocation the output was (tools/rec_variance*.py).  Never more than 4 per CU for the
+    // plain form, though: with the 4-element code prefetch 7 workgroups fit, and 1792 concurrent store streams
+    // write slower than 1024 (100 M rows: 22.3 vs 19.4 ms on one box; a store-only kernel shows the same trend).
+    // The lookup form (random source rows: workgroup times vary, reads matter) takes three rounds of its resident
+    // count in shorter ranges (2.55 ms per 10 M rows against 2.8-2.9 with 4 or 8 per CU).
     // PQHIP_DEBUG_REC_WGS overrides the per-CU count.
     static const int rec_wgs_per_cu = [] { const char* e = getenv("PQHIP_DEBUG_REC_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
     const int64_t nblocks = (n + rows_per_block - 1) / rows_per_block;
     const size_t lds = (((size_t)cpr * (vec ? 4 / gsz : 1) * sizeof(int) + 15) & ~(size_t)15) +
                        (((size_t)2 * rows_per_block * cb->M * code_bytes + 15) & ~(size_t)15) +
                        (sel_rows ? (size_t)2 * rows_per_block * sizeof(float) : 0);
-#define LAUNCH_REC2(IDX, V, GG)                                                                   \
+#define LAUNCH_REC3(IDX, V, GG, NEE)                                                              \
     do {                                                                                          \
         const int per_cu = rec_wgs_per_cu ? rec_wgs_per_cu                                        \
-            : sel_rows ? 3 * resident_wgs((const void*)k_reconstruct<IDX, V, true, GG>, lds)      \
-                       : resident_wgs((const void*)k_reconstruct<IDX, V, false, GG>, lds);        \
+            : sel_rows ? 3 * resident_wgs((const void*)k_reconstruct<IDX, V, true, GG, NEE>, lds) \
+                       : std::min(4, resident_wgs((const void*)k_reconstruct<IDX, V, false, GG, NEE>, lds)); \
         const unsigned grid = (unsigned)std::min<int64_t>(nblocks, (int64_t)cus_of(cb, slot) * per_cu); \
         if (sel_rows)                                                                             \
-            hipLaunchKernelGGL((k_reconstruct<IDX, V, true, GG>), dim3(grid), dim3(256), lds, st, \
+            hipLaunchKernelGGL((k_reconstruct<IDX, V, true, GG, NEE>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
                                (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
                                sel_rows, n_codes, sel_scales);                                    \
         else                                                                                      \
-            hipLaunchKernelGGL((k_reconstruct<IDX, V, false, GG>), dim3(grid), dim3(256), lds, st, \
+            hipLaunchKernelGGL((k_reconstruct<IDX, V, false, GG, NEE>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
                                (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
                                (const int64_t*)nullptr, (int64_t)0, (const float*)nullptr);       \
+    } while (0)
+#define LAUNCH_REC2(IDX, V, GG)                                                                   \
+    do {                                                                                          \
+        if ((int64_t)rows_per_block * cb->M <= 256 * 4) LAUNCH_REC3(IDX, V, GG, 4);               \
+        else LAUNCH_REC3(IDX, V, GG, 16);                                                         \
     } while (0)
 #define LAUNCH_REC(IDX)                                                                           \
     do {                                                                                          \
@@ -1095,6 +1103,7 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     if (code_bytes == 1) LAUNCH_REC(uint8_t);
     else if (code_bytes == 4) LAUNCH_REC(uint32_t);
     else return PQHIP_EUNSUPPORTED;
+#undef LAUNCH_REC3
 #undef LAUNCH_REC2
 #undef LAUNCH_REC
     HIPCHK(hipGetLastError());
