@@ -55,8 +55,9 @@ thread_local std::string g_hip_err;
 
 constexpr int64_t kStageBytes = 256ll << 20;   // input bytes per pinned staging buffer of a host-resident call (two per device)
 constexpr int64_t kStageRowsMin = 4096;
-constexpr int64_t kScratchBytesMax = 4ll << 30;   // one leased scratch buffer: <= 4 GiB (larger batches are chunked; every chunk
-                                                  // boundary costs two kernel tails, ~0.3 ms: 10 M x 300 rows = 3 chunks)
+constexpr int64_t kScratchBytesMax = 4ll << 30;   // upper bound of one leased scratch buffer; the OPQ paths take far less
+                                                  // (opq_chunk_rows: ~1.2 M rows, whole rounds of the rotation grid)
+constexpr int kRot6RowsPerWg = 12 * 32 * 12;      // k_rotate_pblock6: 12 waves x 12 tiles of 32 rows per workgroup
 constexpr int kScratchPoolMax = 3;                // leased scratch buffers per (codebook, device): <= 12 GiB of the 288 GB HBM,
                                                   // and only while that many callers are inside OPQ calls at once
 constexpr int kErrSlots = 64;                     // per-stream "code >= K" flags per (codebook, device)
@@ -539,7 +540,7 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         static const bool use_v6 = getenv("PQHIP_DEBUG_NO_GEMM6") == nullptr;
         const bool out_vec6 = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
         if (use_v6 && vec && out_vec6 && lds6 <= 160 * 1024) {
-            const int rows_per_wg = 12 * 32 * 12;     // 12 tiles per wave
+            const int rows_per_wg = kRot6RowsPerWg;   // 12 tiles per wave
             const int ncb = (d + 63) / 64;
             const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
             const int64_t rg_per_xcd = (n_rg + 7) / 8;
@@ -1110,6 +1111,28 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     return PQHIP_OK;
 }
 
+// Rows per chunk of the OPQ paths (rotation through a leased scratch buffer).  The rotation kernel runs one
+// 12-wave workgroup per CU, (d / 64) column blocks x row groups of 4,608 rows, the column blocks of a row group on
+// one XCD: a chunk whose workgroups fill every XCD's CUs a whole number of times leaves no partial last round.
+// Measured on 10 M x 300 (rotate + encode, one box): 3.58 M rows (the 4 GiB cap: 15.3 rounds) 33.2 ms, 3.54 M
+// (15 rounds) 32.5, 2.36 M (10) 32.2, 1.18 M (5) 32.0-32.2, 0.59 M (2.5 rounds) 34.8; one 12 GB chunk 50.9 ms.
+int64_t opq_chunk_rows(pqhip_codebook* cb, int slot, int64_t n)
+{
+    static const int64_t dbg_rows = [] { const char* e = getenv("PQHIP_DEBUG_SCRATCH_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    const int64_t cap_rows = std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float)));
+    if (dbg_rows) return std::min<int64_t>(n, std::min<int64_t>(dbg_rows, cap_rows));
+    const int ncb = (int)((cb->d + 63) / 64);
+    const int slots_per_xcd = std::max(1, cb->ctx->devs[slot]->n_cus / 8);
+    int g = slots_per_xcd, b = ncb;                 // gcd
+    while (b) { const int t = g % b; g = b; b = t; }
+    const int64_t unit_rg = 8ll * (slots_per_xcd / g);          // row groups per balanced unit (all 8 XCDs)
+    const int64_t cap_rg = cap_rows / kRot6RowsPerWg;
+    const int64_t want_rg = 8ll * slots_per_xcd;                // 256 row groups = 1.18 M rows on a 256-CU device
+    const int64_t chunk_rg = std::max<int64_t>(unit_rg, std::min<int64_t>(cap_rg, want_rg) / unit_rg * unit_rg);
+    const int64_t rows = chunk_rg * kRot6RowsPerWg;
+    return std::min<int64_t>(n, std::min<int64_t>(rows, cap_rows));
+}
+
 int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
                           void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st)
 {
@@ -1167,7 +1190,7 @@ int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_
         if (cb->variant == 5) return PQHIP_EUNSUPPORTED;
     }
     // otherwise: rx = x.dot(P) into a leased scratch buffer, chunked, then PQ encode of rx
-    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
+    const int64_t chunk = opq_chunk_rows(cb, slot, n);
     ScratchLease rx(cb, slot, st);
     PQCHK(rx.acquire((size_t)chunk * cb->d * sizeof(float)));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
@@ -1192,7 +1215,7 @@ int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, 
         return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st, err, sel_rows, n_codes, sel_scales);
     // OPQ (pq.rs:323-326): gather into a leased scratch buffer, then out = r.dot(P^T); a lookup's scale comes last
     CodebookDev& cd = cb->dev[slot];
-    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(1, kScratchBytesMax / (cb->d * (int64_t)sizeof(float))));
+    const int64_t chunk = opq_chunk_rows(cb, slot, n);
     ScratchLease rec(cb, slot, st);
     PQCHK(rec.acquire((size_t)chunk * cb->d * sizeof(float)));
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
