@@ -4,6 +4,9 @@
 #include <type_traits>
 #include "kernels_mfma.hip.h"
 
+#ifndef ROT_ABLATE
+#define ROT_ABLATE 0      // timing experiments only (results wrong): 1 no global stores, 2 no epilogue at all, 3 no x fetch/stash, 4 no LDS operand reads after the first group
+#endif
 namespace pqhip {
 
 // ---------------------------------------------------------------------------------------------
@@ -504,6 +507,11 @@ __global__ __launch_bounds__(512, 2) void k_rotate_pblock5(const float* __restri
 // launch lies outside the tile loops (P staging per workgroup, workgroup turnover, chunk tails).  Measured
 // equal to v5 within 1 % (34.1-34.5 vs 34.3-34.8 ms for rotate + encode of 10 M rows); starting the three
 // waves of a SIMD a third of a tile apart changed nothing.
+// Timing ablations (-DROT_ABLATE=n, results wrong by construction; tools/rot_time.py, 1.18 M x 300 rows, one box):
+// shipped 2.34 ms; no global stores 2.20; no x fetch from global memory 2.02 (-14 %: every row is fetched by the
+// five column-block workgroups, 64 bytes = half a cache line per slab); no LDS operand reads after the first
+// group 2.42 (the LDS reads are NOT what binds); a slab row stride without the 2-way bank conflict of the x
+// operand reads (18 instead of 20 floats): no change.
 // Requires 16-byte aligned rows and d % 4 == 0, like v5.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(768, 3) void k_rotate_pblock6(const float* __restrict__ x, int64_t n,
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock6(const float* __restri
         for (int i = 0; i < 2; ++i) {
             const int k = KS * slab + 4 * lc;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < d) v = *reinterpret_cast<const f32x4*>(rp[i] + KS * slab);
+            if (k < d && ROT_ABLATE != 3) v = *reinterpret_cast<const f32x4*>(rp[i] + KS * slab);
             st[i] = v;
         }
     };
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock6(const float* __restri
     auto xaddr = [&](int slab) { return xs + ((size_t)(slab & 1) * 32 + j) * XS + 2 * h; };
     f32x2 xa, pa0, pa1, xb, pb0, pb1;
 #define PQ6_RD(X, P0, P1, SLAB, U)                                                  \
-    {                                                                               \
+    if (ROT_ABLATE != 4 || ((SLAB) == 0 && (U) < 2)) {                              \
         const float* ar_ = xaddr(SLAB) + 4 * (U);                                   \
         const float* pq_ = plane + ((SLAB) * (KS / 4) + (U)) * 256;                 \
         X = *reinterpret_cast<const f32x2*>(ar_);                                   \
@@ -686,8 +694,9 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock6(const float* __restri
         // 64 predicated stores per tile made the k loop 30 % longer.)
         float* os = xs;
         const int er = lane >> 3, ec = lane & 7;     // rows er + 8 i, 16-byte piece ec of a 32-column tile
+        if (ROT_ABLATE == 2) asm volatile("" ::"v"(tot0), "v"(tot1));
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < 2 && ROT_ABLATE != 2; ++ct) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 os[((r & 3) + 8 * (r >> 2) + 4 * h) * OS + j] = ct ? tot1[r] : tot0[r];
@@ -696,6 +705,7 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock6(const float* __restri
                 const int rr = er + 8 * i;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(os + rr * OS + 4 * ec);
                 const int col = col0 + 32 * ct + 4 * ec;
+                if (ROT_ABLATE == 1) { asm volatile("" ::"v"(v)); continue; }
                 if (rr < left && col < d)
                     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + (row0 + rr) * o_rs + col));
             }
