@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-configs", action="store_true",
                     help="headline only: skip the configs[2..4] sub-records of the default run")
-    ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of every sub-config")
+    ap.add_argument("--sub-steps", type=int, default=10, help="timed steps of every sub-config (after 2 warm-up steps)")
     ap.add_argument("--in-process", type=int, default=0, metavar="N",
                     help="drive the library's own row sharder over N device slots from ONE process and one host batch")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -144,6 +144,7 @@ class Bench:
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         per = [a.elapsed_time(b) for a, b in evs]
+        self.last_launch_ms = [round(v, 3) for v in per]
         return elapsed, sum(per) / len(per), min(per), max(per)
 
     def normal_rows(self, rows, d, seed):
@@ -260,6 +261,8 @@ class Bench:
                     "avg_launch_ms": kernel_ms, "min_launch_ms": kmin, "max_launch_ms": kmax,
                     "algorithmic_flop_per_vector": flop, "algorithmic_bytes_per_vector": bytes_vec,
                     "hbm_gbs": bytes_vec * rows / sec / 1e9, "hbm_frac": bytes_vec * rows / sec / 1e9 / PEAK_HBM_GBS}
+        if workload != "kmeans":
+            roof["launch_ms"] = list(getattr(self, "last_launch_ms", []))[:32]     # every timed step, in order
         if traffic_rec:
             roof["traffic_kernel"] = traffic_rec.get("kernel")
             roof["traffic_over_algorithmic"] = traffic / float(bytes_vec * rows)
@@ -396,7 +399,7 @@ def main():
                                    ("configs[4]_one_gpu_shard", "encode_d768", 12_500_000)):
                 sd, sm, sk = WORKLOADS[wl][1]
                 try:
-                    r = b.run(wl, srows, sd, sm, sk, max(1, min(args.steps, args.sub_steps)), 1)
+                    r = b.run(wl, srows, sd, sm, sk, max(1, min(args.steps, args.sub_steps)), min(2, max(1, args.warmup)))
                     subs[key] = record(wl, r, 1)
                 except Exception as e:            # a sub-config must never take the headline line down
                     subs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
