@@ -1115,7 +1115,7 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
 // 12-wave workgroup per CU, (d / 64) column blocks x row groups of 4,608 rows, the column blocks of a row group on
 // one XCD: a chunk whose workgroups fill every XCD's CUs a whole number of times leaves no partial last round.
 // Measured on 10 M x 300 (rotate + encode, one box): 3.58 M rows (the 4 GiB cap: 15.3 rounds) 33.2 ms, 3.54 M
-// (15 rounds) 32.5, 2.36 M (10) 32.2, 1.18 M (5) 32.0-32.2, 0.59 M (2.5 rounds) 34.8; one 12 GB chunk 50.9 ms.
+// (15 rounds) 32.5, 2.36 M (10) 32.2, 1.18 M (5) 32.0-32.2, 0.59 M (2.5 rounds) 34.8; one 12 GB chunk 33.1-33.5 ms.
 int64_t opq_chunk_rows(pqhip_codebook* cb, int slot, int64_t n)
 {
     static const int64_t dbg_rows = [] { const char* e = getenv("PQHIP_DEBUG_SCRATCH_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
