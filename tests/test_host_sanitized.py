@@ -21,8 +21,12 @@ def test_host_logic_under_asan_ubsan_with_mock_hip():
     assert build.returncode == 0, build.stderr[-3000:]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:halt_on_error=1",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
-    run = subprocess.run([os.path.join(MOCK, "build", "san_driver")], capture_output=True, text=True, env=env, timeout=900)
-    out = run.stdout + run.stderr
-    assert run.returncode == 0, out[-4000:]
-    assert "all checks passed" in out
-    assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-4000:]
+    # twice: with the library's own chunk sizes, and with 1,000-row OPQ scratch chunks so that every OPQ call of the
+    # driver walks many chunks and a remainder through one lease (the chunk loop of quantize_dev_impl / reconstruct_dev_impl)
+    for extra in ({}, {"PQHIP_DEBUG_SCRATCH_ROWS": "1000"}):
+        run = subprocess.run([os.path.join(MOCK, "build", "san_driver")], capture_output=True, text=True,
+                             env=dict(env, **extra), timeout=900)
+        out = run.stdout + run.stderr
+        assert run.returncode == 0, out[-4000:]
+        assert "all checks passed" in out
+        assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-4000:]
