@@ -25,6 +25,7 @@
 #include "kernels_basic.hip.h"
 #include "kernels_mfma.hip.h"
 #include "kernels_rotate.hip.h"
+#include "kernels_rotate8.hip.h"
 #include "kernels_kmeans.hip.h"
 #include "kernels_adc.hip.h"
 #include "encode_launch.h"
@@ -534,6 +535,65 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
     const bool vec = (d % 4 == 0) && (x_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
     const int kpad = (d + 3) & ~3;
     const size_t pblock_bytes = (size_t)kpad * 64 * sizeof(float);
+    {
+        // v8: P block in LDS, x rows straight from global memory into the MFMA operands, direct 16-byte stores
+        // from the accumulators (kernels_rotate8.hip.h); same launch geometry as v6
+        const size_t lds8 = ((size_t)((d + 3) / 4) + 1) * 256 * sizeof(float) + 16;   // P image + spare group + tile counter
+        static const bool use_v8 = getenv("PQHIP_DEBUG_NO_GEMM8") == nullptr;
+        const bool out_vec8 = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
+        if (use_v8 && vec && out_vec8 && lds8 <= 160 * 1024) {
+            const int rows_per_wg = kRot6RowsPerWg;   // 12 waves x 12 tiles of 32 rows
+            const int ncb = (d + 63) / 64;
+            const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
+            const int64_t rg_per_xcd = (n_rg + 7) / 8;
+            const dim3 grid((unsigned)(rg_per_xcd * ncb * 8));
+            static const bool want_stamps = getenv("PQHIP_DEBUG_ROT_STAMP") != nullptr;
+            DevBuf stamp_buf;
+            const size_t n_stamp = (size_t)grid.x * 12 * 8;
+            if (want_stamps) {
+                PQCHK(stamp_buf.alloc(n_stamp * sizeof(unsigned long long)));
+                HIPCHK(hipMemsetAsync(stamp_buf.p, 0, n_stamp * sizeof(unsigned long long), st));
+            }
+            static const int dyn_tiles = getenv("PQHIP_DEBUG_ROT8_STATIC") == nullptr;
+            // template facts: rule-2 split (d > 256), odd number of full 32-k bursts, partial last burst
+            const bool splitk = d > kKC, odd = ((d >> 5) & 1) != 0, tail = (d & 31) != 0;
+#define LAUNCH_ROT8(S, O, T)                                                                                        \
+            do {                                                                                                    \
+                HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock8<S, O, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                hipLaunchKernelGGL((k_rotate_pblock8<S, O, T>), grid, dim3(768), lds8, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, \
+                                   rg_per_xcd, dyn_tiles, (unsigned long long*)stamp_buf.p);                        \
+            } while (0)
+            if (splitk) { if (odd) { if (tail) LAUNCH_ROT8(true, true, true); else LAUNCH_ROT8(true, true, false); }
+                          else     { if (tail) LAUNCH_ROT8(true, false, true); else LAUNCH_ROT8(true, false, false); } }
+            else        { if (odd) { if (tail) LAUNCH_ROT8(false, true, true); else LAUNCH_ROT8(false, true, false); }
+                          else     { if (tail) LAUNCH_ROT8(false, false, true); else LAUNCH_ROT8(false, false, false); } }
+#undef LAUNCH_ROT8
+            HIPCHK(hipGetLastError());
+            if (want_stamps) {   // diagnostics: synchronous summary on stderr
+                std::vector<unsigned long long> h(n_stamp);
+                HIPCHK(hipMemcpyAsync(h.data(), stamp_buf.p, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                double tiles = 0, kc = 0, ec = 0, cyc = 0, rt = 0, cmax = 0, cmin = 1e30, wgmax = 0, first = 0, last = 0; size_t waves = 0, wgs = 0;
+                for (size_t w0 = 0; w0 < n_stamp; w0 += 12 * 8) {
+                    double m = 0;
+                    for (size_t i = w0; i < w0 + 12 * 8; i += 8)
+                        if (h[i]) {
+                            tiles += (double)h[i]; kc += (double)h[i + 1]; ec += (double)h[i + 2]; cyc += (double)h[i + 3]; rt += (double)h[i + 4]; ++waves;
+                            first += (double)h[i + 6]; last += (double)h[i + 7];
+                            cmax = std::max(cmax, (double)h[i + 3]); cmin = std::min(cmin, (double)h[i + 3]); m = std::max(m, (double)h[i + 3]);
+                        }
+                    if (m > 0) { wgmax += m; ++wgs; }
+                }
+                if (tiles > 0)
+                    fprintf(stderr, "[pqhip] rotate v8 stamps: %zu waves, %.1f tiles/wave, tile %.0f cyc (first %.0f, last %.0f), P staging %.0f cyc/wave, wave life %.0f cyc (min %.0f, max %.0f; slowest wave of a workgroup %.0f), clock %.0f MHz\n",
+                            waves, tiles / waves, kc / tiles, first / waves, last / waves, ec / waves, cyc / waves, cmin, cmax, wgmax / wgs, rt > 0 ? cyc / rt * 100.0 : 0.0);
+                if (const char* f = getenv("PQHIP_DEBUG_ROT_STAMP_FILE")) {
+                    if (FILE* fp = fopen(f, "ab")) { fwrite(h.data(), sizeof(unsigned long long), n_stamp, fp); fclose(fp); }
+                }
+            }
+            return PQHIP_OK;
+        }
+    }
     {
         // v6: as v5 with three waves per SIMD (12-wave workgroups, 16-k slabs)
         const size_t lds6 = ((size_t)((d + 3) / 4) * 256 + (size_t)12 * 2 * 32 * 20) * sizeof(float);
