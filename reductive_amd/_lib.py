@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libpqhip.so")
+_SO = os.environ.get("PQHIP_LIB") or os.path.join(_HERE, "libpqhip.so")   # PQHIP_LIB: A/B of two builds on one box (tools/)
 _lib = None
 
 OK, EINVAL, ESHAPE, ECODE_RANGE, EINDEX_WIDTH, ENODEV, EHIP, ENOMEM, EUNSUPPORTED = range(9)

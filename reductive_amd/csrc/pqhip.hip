@@ -59,6 +59,12 @@ constexpr int64_t kStageRowsMin = 4096;
 constexpr int64_t kScratchBytesMax = 4ll << 30;   // upper bound of one leased scratch buffer; the OPQ paths take far less
                                                   // (opq_chunk_rows: ~1.2 M rows, whole rounds of the rotation grid)
 constexpr int kRot6RowsPerWg = 12 * 32 * 12;      // k_rotate_pblock6: 12 waves x 12 tiles of 32 rows per workgroup
+// rows per workgroup of the P-block rotation kernels (v6, v8) and of the OPQ chunking built on it; PQHIP_DEBUG_ROT_RPW overrides
+int rot_rows_per_wg()
+{
+    static const int v = [] { const char* e = getenv("PQHIP_DEBUG_ROT_RPW"); const int r = e ? atoi(e) : 0; return r >= 384 ? (r / 384) * 384 : kRot6RowsPerWg; }();
+    return v;
+}
 constexpr int kScratchPoolMax = 3;                // leased scratch buffers per (codebook, device): <= 12 GiB of the 288 GB HBM,
                                                   // and only while that many callers are inside OPQ calls at once
 constexpr int kErrSlots = 64;                     // per-stream "code >= K" flags per (codebook, device)
@@ -542,7 +548,7 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         static const bool use_v8 = getenv("PQHIP_DEBUG_NO_GEMM8") == nullptr;
         const bool out_vec8 = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
         if (use_v8 && vec && out_vec8 && lds8 <= 160 * 1024) {
-            const int rows_per_wg = kRot6RowsPerWg;   // 12 waves x 12 tiles of 32 rows
+            const int rows_per_wg = rot_rows_per_wg();   // 12 waves x 12 tiles of 32 rows
             const int ncb = (d + 63) / 64;
             const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
             const int64_t rg_per_xcd = (n_rg + 7) / 8;
@@ -600,7 +606,7 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         static const bool use_v6 = getenv("PQHIP_DEBUG_NO_GEMM6") == nullptr;
         const bool out_vec6 = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
         if (use_v6 && vec && out_vec6 && lds6 <= 160 * 1024) {
-            const int rows_per_wg = kRot6RowsPerWg;   // 12 tiles per wave
+            const int rows_per_wg = rot_rows_per_wg();   // 12 tiles per wave
             const int ncb = (d + 63) / 64;
             const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
             const int64_t rg_per_xcd = (n_rg + 7) / 8;
@@ -1186,10 +1192,10 @@ int64_t opq_chunk_rows(pqhip_codebook* cb, int slot, int64_t n)
     int g = slots_per_xcd, b = ncb;                 // gcd
     while (b) { const int t = g % b; g = b; b = t; }
     const int64_t unit_rg = 8ll * (slots_per_xcd / g);          // row groups per balanced unit (all 8 XCDs)
-    const int64_t cap_rg = cap_rows / kRot6RowsPerWg;
+    const int64_t cap_rg = cap_rows / rot_rows_per_wg();
     const int64_t want_rg = 8ll * slots_per_xcd;                // 256 row groups = 1.18 M rows on a 256-CU device
     const int64_t chunk_rg = std::max<int64_t>(unit_rg, std::min<int64_t>(cap_rg, want_rg) / unit_rg * unit_rg);
-    const int64_t rows = chunk_rg * kRot6RowsPerWg;
+    const int64_t rows = chunk_rg * rot_rows_per_wg();
     return std::min<int64_t>(n, std::min<int64_t>(rows, cap_rows));
 }
 
