@@ -404,10 +404,33 @@ def main():
                 except Exception as e:            # a sub-config must never take the headline line down
                     subs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             rec["configs"] = subs
+        if use_gpu:
+            rec["summary"] = summarize(rec)       # LAST key: the tail of the line always shows every BASELINE config
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def summarize(rec):
+    """Compact per-config digest (<= 600 characters), emitted as the last key of the JSON line: value, roofline
+    fraction, measured-over-algorithmic HBM traffic and the parity flag of the headline and of every sub-config."""
+    def parity(r):
+        cb = r.get("cpu_baseline") or {}
+        flags = [v for k_, v in cb.items() if k_.startswith("gpu_") and isinstance(v, bool)]
+        return all(flags) if flags else None
+
+    def one(r):
+        if "error" in r:
+            return {"error": r["error"][:60]}
+        roof = r.get("roofline") or {}
+        tr = roof.get("traffic_over_algorithmic")
+        return {"v": float("%.4g" % r["value"]), "frac": round(roof.get("frac", 0.0), 3), "bound": roof.get("bound"),
+                "traffic_ratio": None if tr is None else round(tr, 2), "parity": parity(r)}
+    out = {"configs[1]": one(rec)}
+    for key, sub in (rec.get("configs") or {}).items():
+        out[key.replace("_one_gpu_shard", "")] = one(sub)
+    return out
 
 
 def in_process(args, d, m, k, rows):

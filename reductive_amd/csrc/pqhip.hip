@@ -207,8 +207,10 @@ struct CodebookDev {
     float* PT = nullptr;     // [d][d]   r.dot(P^T)
     int* err = nullptr;      // [0] unused, [1] "some ||c||^2 not finite" (k_check_norms), [2 .. 2 + kErrSlots):
                              // "code >= K / row index out of range seen by reconstruct", one flag per caller stream
-    std::vector<hipStream_t> err_streams;  // stream of flag slot i (under cb->mu); more streams than slots share the last
-    std::vector<ScratchBuf> pool;          // under cb->mu
+    std::vector<hipStream_t> err_streams;  // stream of flag slot i (under cb->mu); least recently used slot is recycled
+    std::vector<uint64_t> err_used;        // last use of slot i (err_clock ticks)
+    uint64_t err_clock = 0;
+    std::vector<ScratchBuf> pool;          // under cb->mu; capacity kScratchPoolMax reserved at creation (elements never move)
 };
 
 }  // namespace
@@ -290,8 +292,12 @@ struct DevBuf {
 // an idle buffer that is large enough; an idle buffer that has to grow (or a new one while the pool is
 // below kScratchPoolMax); otherwise the call queues behind a buffer whose work is still in flight
 // (stream order through its event) or, when every buffer is leased to another host thread, waits for a
-// release.  On return the buffer is exclusively this call's until release_scratch().
-int32_t lease_scratch(pqhip_codebook* cb, int slot, size_t bytes, hipStream_t st, int* out_idx)
+// release.  On return the buffer is exclusively this call's until release_scratch(), and *out_p is its
+// device pointer (copied under the mutex: the pool vector may be touched by other threads afterwards).
+// Nothing that can block for long -- hipEventSynchronize on the old buffer's work, hipFree, a <= 4 GiB
+// hipMalloc -- runs under cb->mu: the buffer is first marked leased (nobody else can pick it), then resized
+// with the mutex released, so other callers of the codebook (and every release_scratch) keep moving.
+int32_t lease_scratch(pqhip_codebook* cb, int slot, size_t bytes, hipStream_t st, int* out_idx, void** out_p)
 {
     CodebookDev& cd = cb->dev[slot];
     std::unique_lock<std::mutex> lk(cb->mu);
@@ -312,7 +318,8 @@ int32_t lease_scratch(pqhip_codebook* cb, int slot, size_t bytes, hipStream_t st
         if (pick < 0 && (int)cd.pool.size() < kScratchPoolMax) {
             ScratchBuf nb;
             HIPCHK(hipEventCreateWithFlags(&nb.done, hipEventDisableTiming));
-            cd.pool.push_back(nb);   // empty: grown below (a never-recorded event counts as complete)
+            cd.pool.push_back(nb);   // empty: grown below (a never-recorded event counts as complete); capacity is
+                                     // reserved at codebook creation, so elements never move
             pick = (int)cd.pool.size() - 1;
         }
         if (pick < 0) pick = idle_any >= 0 ? idle_any : busy_fit >= 0 ? busy_fit : busy_any;
@@ -320,18 +327,44 @@ int32_t lease_scratch(pqhip_codebook* cb, int slot, size_t bytes, hipStream_t st
             cb->cv.wait(lk);
             continue;
         }
-        ScratchBuf& b = cd.pool[pick];
-        if (b.bytes < bytes) {
-            // not leased, so no host thread holds this pointer; wait for the device work that still
-            // uses it, then replace it
-            HIPCHK(hipEventSynchronize(b.done));
-            if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
-            HIPCHK(hipMalloc(&b.p, bytes));
+        cd.pool[pick].leased = true;
+        if (cd.pool[pick].bytes < bytes) {
+            // leased to us, so no other host thread holds or can take this buffer: wait for the device work that
+            // still uses the old allocation and replace it, with the mutex released
+            hipEvent_t done = cd.pool[pick].done;
+            void* old = cd.pool[pick].p;
+            lk.unlock();
+            hipError_t e = hipEventSynchronize(done);
+            bool freed = false;
+            if (e == hipSuccess && old) { e = hipFree(old); freed = e == hipSuccess; }
+            void* np = nullptr;
+            if (e == hipSuccess) e = hipMalloc(&np, bytes);
+            lk.lock();
+            ScratchBuf& b = cd.pool[pick];
+            if (e != hipSuccess) {
+                if (freed) { b.p = nullptr; b.bytes = 0; }   // (otherwise the old allocation stays on record)
+                b.leased = false;
+                lk.unlock();
+                cb->cv.notify_one();
+                g_hip_err = std::string("lease_scratch: ") + hipGetErrorString(e);
+                (void)hipGetLastError();
+                return (e == hipErrorOutOfMemory) ? PQHIP_ENOMEM : PQHIP_EHIP;
+            }
+            b.p = np;
             b.bytes = bytes;
         }
-        b.leased = true;
-        HIPCHK(hipStreamWaitEvent(st, b.done, 0));
+        ScratchBuf& b = cd.pool[pick];
+        const hipError_t e = hipStreamWaitEvent(st, b.done, 0);
+        if (e != hipSuccess) {
+            b.leased = false;
+            lk.unlock();
+            cb->cv.notify_one();
+            g_hip_err = std::string("hipStreamWaitEvent(scratch): ") + hipGetErrorString(e);
+            (void)hipGetLastError();
+            return PQHIP_EHIP;
+        }
         *out_idx = pick;
+        *out_p = b.p;
         return PQHIP_OK;
     }
 }
@@ -351,24 +384,39 @@ struct ScratchLease {
     pqhip_codebook* cb;
     int slot, idx = -1;
     hipStream_t st;
+    void* p = nullptr;       // the leased buffer (copied under cb->mu by lease_scratch; never read from the pool again)
     ScratchLease(pqhip_codebook* c, int s, hipStream_t t) : cb(c), slot(s), st(t) {}
     ~ScratchLease() { if (idx >= 0) release_scratch(cb, slot, idx, st); }
-    int32_t acquire(size_t bytes) { return lease_scratch(cb, slot, bytes, st, &idx); }
-    void* ptr() const { return cb->dev[slot].pool[idx].p; }  // stable while leased (vector elements are never erased; growth happens under cb->mu before the pointer is read)
+    int32_t acquire(size_t bytes) { return lease_scratch(cb, slot, bytes, st, &idx, &p); }
+    void* ptr() const { return p; }
 };
 
-// device flag of "code >= K / row index out of range" for calls on stream `st`
+// device flag of "code >= K / row index out of range" for calls on stream `st`.  One slot per caller stream; when all
+// kErrSlots are taken the least recently used one is handed to the new stream and cleared ON THAT STREAM first (a
+// pending error of a stream that has not been seen for kErrSlots other streams is dropped rather than delivered to
+// the wrong caller; a destroyed and re-created stream with the same handle value keeps its slot -- callers that check
+// after every call, the default of the Python / C++ / Rust mirrors, never leave one pending).
 int* err_flag_for(pqhip_codebook* cb, int slot, hipStream_t st)
 {
     CodebookDev& cd = cb->dev[slot];
     std::lock_guard<std::mutex> g(cb->mu);
+    const uint64_t now = ++cd.err_clock;
     int i = 0;
     for (; i < (int)cd.err_streams.size(); ++i)
         if (cd.err_streams[i] == st) break;
     if (i == (int)cd.err_streams.size()) {
-        if (i < kErrSlots) cd.err_streams.push_back(st);
-        else i = kErrSlots - 1;
+        if (i < kErrSlots) {
+            cd.err_streams.push_back(st);
+            cd.err_used.push_back(now);
+        } else {
+            i = 0;
+            for (int k = 1; k < kErrSlots; ++k)
+                if (cd.err_used[k] < cd.err_used[i]) i = k;
+            cd.err_streams[i] = st;
+            (void)hipMemsetAsync(cd.err + 2 + i, 0, sizeof(int), st);
+        }
     }
+    cd.err_used[i] = now;
     return cd.err + 2 + i;
 }
 
@@ -798,6 +846,7 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
     }
 
     cb->dev.resize(ctx->devs.size());
+    for (CodebookDev& cd : cb->dev) cd.pool.reserve(kScratchPoolMax);
     bool norms_ok = true;
     for (size_t i = 0; i < ctx->devs.size(); ++i) {
         if (only_slot >= 0 && (int)i != only_slot) continue;
@@ -1331,11 +1380,24 @@ int pack_threads(size_t n_devs)
     return (int)std::max<unsigned>(1, std::min<unsigned>(cap, hw / (unsigned)std::max<size_t>(1, n_devs)));
 }
 
-// rows per pinned staging buffer for rows of `row_bytes` input bytes
+// rows per pinned staging buffer for rows of `row_bytes` input bytes: kStageBytes worth of rows, at least
+// kStageRowsMin of them only while that floor stays within 4 x kStageBytes (very wide rows: the byte cap wins,
+// down to one row per buffer)
 int64_t stage_rows(int64_t shard_rows, int64_t row_bytes)
 {
-    const int64_t r = std::max<int64_t>(kStageRowsMin, kStageBytes / std::max<int64_t>(1, row_bytes));
+    row_bytes = std::max<int64_t>(1, row_bytes);
+    int64_t r = kStageBytes / row_bytes;
+    if (r < kStageRowsMin) r = std::min<int64_t>(kStageRowsMin, std::max<int64_t>(1, 4 * kStageBytes / row_bytes));
     return std::max<int64_t>(1, std::min<int64_t>(r, shard_rows));
+}
+
+// the pinned staging buffers of a device slot are reused from call to call: an earlier call that returned on an error
+// may have left copies in flight on the staging streams
+int32_t quiesce_staging(DeviceSlot& ds)
+{
+    HIPCHK(hipStreamSynchronize(ds.stream[0]));
+    HIPCHK(hipStreamSynchronize(ds.stream[1]));
+    return PQHIP_OK;
 }
 
 void store_code(void* base, int bytes, int64_t off, uint32_t v)
@@ -1662,6 +1724,7 @@ int32_t pqhip_quantize_batch_f32(pqhip_codebook* cb, const float* x, int64_t n, 
         DeviceSlot& ds = *cb->ctx->devs[slot];
         std::lock_guard<std::mutex> g(ds.mu);
         SET_DEVICE(ds.ordinal);
+        PQCHK(quiesce_staging(ds));
         const int64_t cap = stage_rows(re - rb, d * (int64_t)sizeof(float));
         for (int b = 0; b < 2; ++b)
             PQCHK(ensure_staging(ds.st[b], (size_t)cap * d * sizeof(float), (size_t)cap * M * dev_bytes));
@@ -1734,6 +1797,7 @@ int32_t pqhip_reconstruct_batch_f32(pqhip_codebook* cb, const void* codes, int32
         DeviceSlot& ds = *cb->ctx->devs[slot];
         std::lock_guard<std::mutex> g(ds.mu);
         SET_DEVICE(ds.ordinal);
+        PQCHK(quiesce_staging(ds));
         const int64_t cap = stage_rows(re - rb, d * (int64_t)sizeof(float));   // sized by the OUTPUT rows here
         for (int b = 0; b < 2; ++b)
             PQCHK(ensure_staging(ds.st[b], (size_t)cap * M * dev_bytes, (size_t)cap * d * sizeof(float)));
@@ -1850,6 +1914,7 @@ int32_t pqhip_matrix_upload_f32(pqhip_ctx* ctx, int32_t slot, const float* x, in
     m->ctx = ctx; m->slot = slot; m->rows = n; m->cols = d;
     std::lock_guard<std::mutex> g(ds.mu);
     SET_DEVICE(ds.ordinal);
+    PQCHK(quiesce_staging(ds));
     HIPCHK(hipMalloc((void**)&m->d, (size_t)std::max<int64_t>(n, 1) * d * sizeof(float)));
     struct Free { float* p; ~Free() { if (p) (void)hipFree(p); } } guard{m->d};
     const int64_t cap = stage_rows(std::max<int64_t>(n, 1), d * (int64_t)sizeof(float));

@@ -6,14 +6,72 @@
 // the C ABI promises".
 #include <cstdint>
 #include <cstdio>
+#include <string>
 #include <thread>
 #include <vector>
 #include "pqhip.h"
 
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
 
-int main()
+// "threads" mode (the ThreadSanitizer build runs only this): many host threads lease, grow and release the scratch
+// buffers of ONE OPQ codebook and ONE K > 256 codebook on both device slots at once, with sizes that force the pool to
+// grow and buffers to be reallocated while other threads hold leases (ScratchLease::ptr() used to read the
+// pool vector without the mutex), and share the per-stream flag table with more streams than it has slots.
+static int threads_mode()
 {
+    pqhip_ctx* ctx = nullptr;
+    CHECK(pqhip_ctx_create(nullptr, 0, &ctx) == PQHIP_OK && pqhip_ctx_n_devices(ctx) == 2);
+    const int64_t M = 6, K = 64, dsub = 10, d = M * dsub;
+    std::vector<float> q((size_t)(M * K * dsub), 0.25f), P((size_t)(d * d), 0.f);
+    for (int64_t i = 0; i < d; ++i) P[(size_t)(i * d + i)] = 1.f;
+    pqhip_codebook *opq = nullptr, *wide = nullptr;
+    CHECK(pqhip_codebook_create(ctx, q.data(), M, K, dsub, P.data(), &opq) == PQHIP_OK);
+    std::vector<float> qw((size_t)(3 * 700 * 8), 0.5f);
+    CHECK(pqhip_codebook_create(ctx, qw.data(), 3, 700, 8, nullptr, &wide) == PQHIP_OK);
+    const int NT = 12;
+    std::vector<std::thread> th;
+    std::vector<int32_t> rc((size_t)NT, -1);
+    for (int t = 0; t < NT; ++t)
+        th.emplace_back([&, t] {
+            int32_t r = PQHIP_OK;
+            for (int it = 0; it < 6 && r == PQHIP_OK; ++it) {
+                const int64_t n = 3000 + 4000 * ((t + it) % 5);           // growing and shrinking requests
+                std::vector<float> xs((size_t)(n * d), 1.f), out((size_t)(n * d));
+                std::vector<uint32_t> c((size_t)(n * M));
+                void* stream = (void*)(intptr_t)(0x100 + 16 * t + it);      // 72 distinct "streams" > 64 flag slots
+                r = pqhip_quantize_batch_f32_dev(opq, (t + it) & 1, xs.data(), n, d, c.data(), 1, M, stream);
+                if (r == PQHIP_OK) r = pqhip_reconstruct_batch_f32_dev(opq, (t + it) & 1, c.data(), 1, n, M, out.data(), d, stream);
+                if (r == PQHIP_OK) r = pqhip_check_codes_dev(opq, (t + it) & 1, stream);
+                std::vector<float> xw((size_t)(n * 24), 1.f);
+                if (r == PQHIP_OK) r = pqhip_quantize_batch_f32_dev(wide, t & 1, xw.data(), n, 24, c.data(), 4, 3, stream);
+            }
+            rc[(size_t)t] = r;
+        });
+    for (auto& t : th) t.join();
+    for (int32_t r : rc) CHECK(r == PQHIP_OK);
+    // host-resident calls from two threads on one context (device-slot mutexes, staging reuse)
+    {
+        std::vector<std::thread> hs;
+        std::vector<int32_t> hr(2, -1);
+        for (int t = 0; t < 2; ++t)
+            hs.emplace_back([&, t] {
+                std::vector<float> xs((size_t)(30000 * d), 1.f);
+                std::vector<uint8_t> c((size_t)(30000 * M));
+                hr[(size_t)t] = pqhip_quantize_batch_f32(opq, xs.data(), 30000, d, 1, c.data(), 1, M, 1);
+            });
+        for (auto& t : hs) t.join();
+        CHECK(hr[0] == PQHIP_OK && hr[1] == PQHIP_OK);
+    }
+    pqhip_codebook_destroy(wide);
+    pqhip_codebook_destroy(opq);
+    pqhip_ctx_destroy(ctx);
+    std::printf("host logic under sanitizers (threads): all checks passed\n");
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc > 1 && std::string(argv[1]) == "threads") return threads_mode();
     int32_t nd = 0;
     CHECK(pqhip_device_count(&nd) == PQHIP_OK && nd == 2);
     pqhip_ctx* ctx = nullptr;

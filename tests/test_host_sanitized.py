@@ -30,3 +30,21 @@ def test_host_logic_under_asan_ubsan_with_mock_hip():
         assert run.returncode == 0, out[-4000:]
         assert "all checks passed" in out
         assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-4000:]
+
+
+def test_host_threads_under_tsan_with_mock_hip():
+    """the scratch-lease pool, the per-stream flag table and the device-slot staging shared by many host
+    threads, under ThreadSanitizer (same mock HIP runtime; only the driver's multi-thread section runs)."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    san = "-fsanitize=thread -fno-omit-frame-pointer"
+    build = subprocess.run(["make", "-C", MOCK, "-s", "-j8", "SAN=" + san, "B=build_tsan"], capture_output=True, text=True, timeout=1500)
+    assert build.returncode == 0, build.stderr[-3000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    for extra in ({}, {"PQHIP_DEBUG_SCRATCH_ROWS": "1000"}):
+        run = subprocess.run([os.path.join(MOCK, "build_tsan", "san_driver"), "threads"], capture_output=True, text=True,
+                             env=dict(env, **extra), timeout=900)
+        out = run.stdout + run.stderr
+        assert run.returncode == 0, out[-4000:]
+        assert "all checks passed" in out
+        assert "ThreadSanitizer" not in out, out[-4000:]
