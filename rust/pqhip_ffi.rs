@@ -13,7 +13,8 @@
 
 use std::any::TypeId;
 use std::os::raw::{c_char, c_void};
-use std::sync::{Mutex, OnceLock};
+use std::sync::atomic::{AtomicU64, Ordering};
+use std::sync::{Arc, Mutex, OnceLock};
 
 use ndarray::{ArrayBase, ArrayView2, ArrayView3, ArrayViewMut2, ArrayViewMut3, Data, Ix2, ShapeBuilder};
 
@@ -65,33 +66,43 @@ const MIN_GPU_ROWS: usize = 4096;
 /// Device images of `Pq<f32>` values, kept OUTSIDE the struct so that `Pq` keeps
 /// `#[derive(Clone, Debug, PartialEq)]` and literal construction (pq.rs:28-32, opq.rs:95-98).
 /// Same policy as include/reductive_amd/codebook_cache.hpp (which the test-suite executes,
-/// tests/cpp/test_codebook_cache.cpp):
+/// tests/cpp/test_codebook_cache.cpp, including 4 threads x 2 quantizers overlapping on one GPU):
+///  * `Pq<f32>` is `Send + Sync`: the cache mutex is held for lookup / insert / evict ONLY, never across
+///    a GPU call or the creation of a device image;
+///  * a lookup returns an `Arc<Image>` PIN: an entry evicted or replaced while calls run on it is
+///    destroyed when the last pin drops (eviction waits for users, users never wait for each other);
 ///  * key = (quantizer data pointer, element count, ORIGINAL projection data pointer or 0, M, K, dsub)
 ///    -- never the address of a temporary copy;
-///  * a hit is trusted only when a 64-bit content hash of quantizers + projection still matches: a
-///    dropped `Pq` whose allocation is reused, or centroids mutated in place during training, replace
-///    the entry (the stale device image is destroyed) instead of returning wrong codes;
-///  * at most `CACHE_CAP` entries, least recently used destroyed: device memory stays bounded.
+///  * a hit is trusted only when a SAMPLED 64-bit content hash (first and last 4 KiB + 256 spread words
+///    of quantizers and projection: microseconds, not the ~70 us a full hash of 667 KB cost per call)
+///    and the GENERATION counter still match; `try_kmeans_iterations` and `train_step`, which rewrite
+///    centroids in place, bump the generation, so a stale image can never be served after them;
+///  * at most `CACHE_CAP` entries, least recently used dropped: device memory stays bounded.
 const CACHE_CAP: usize = 8;
 #[derive(PartialEq, Clone, Copy)]
 struct Key { q: usize, q_len: usize, p: usize, m: usize, k: usize, dsub: usize }
-struct Entry { key: Key, hash: u64, cb: *mut pqhip_codebook }
-struct Handles { ctx: *mut pqhip_ctx, books: Vec<Entry> /* most recently used first */ }
-unsafe impl Send for Handles {}
-static HANDLES: OnceLock<Option<Mutex<Handles>>> = OnceLock::new();
+struct Image(*mut pqhip_codebook);
+unsafe impl Send for Image {}
+unsafe impl Sync for Image {}            // the C ABI's entry points are re-entrant on one codebook handle
+impl Drop for Image { fn drop(&mut self) { unsafe { pqhip_codebook_destroy(self.0) } } }
+struct Entry { key: Key, hash: u64, gen: u64, image: Arc<Image> }
+struct Ctx(*mut pqhip_ctx);
+unsafe impl Send for Ctx {}
+unsafe impl Sync for Ctx {}
+struct Handles { ctx: Ctx, books: Mutex<Vec<Entry>> /* most recently used first */, generation: AtomicU64 }
+static HANDLES: OnceLock<Option<Handles>> = OnceLock::new();
 
-fn handles() -> Option<&'static Mutex<Handles>> {
+fn handles() -> Option<&'static Handles> {
     HANDLES.get_or_init(|| {
         let mut ctx = std::ptr::null_mut();
         if unsafe { pqhip_ctx_create(std::ptr::null(), 0, &mut ctx) } == PQHIP_OK {
-            Some(Mutex::new(Handles { ctx, books: Vec::new() }))
+            Some(Handles { ctx: Ctx(ctx), books: Mutex::new(Vec::new()), generation: AtomicU64::new(0) })
         } else { None }
     }).as_ref()
 }
 
 /// FNV-1a over 8-byte words: change detection, not cryptography (content_hash of codebook_cache.hpp).
-fn content_hash(data: &[f32], mut h: u64) -> u64 {
-    let bytes = unsafe { std::slice::from_raw_parts(data.as_ptr() as *const u8, data.len() * 4) };
+fn content_hash(bytes: &[u8], mut h: u64) -> u64 {
     let mut chunks = bytes.chunks_exact(8);
     for c in &mut chunks {
         h = (h ^ u64::from_ne_bytes(c.try_into().unwrap())).wrapping_mul(0x100000001b3);
@@ -100,10 +111,25 @@ fn content_hash(data: &[f32], mut h: u64) -> u64 {
     for &b in chunks.remainder() { h = (h ^ b as u64).wrapping_mul(0x100000001b3); }
     h
 }
+/// sampled_hash of codebook_cache.hpp: everything when small, else head + tail + 256 spread words.
+fn sampled_hash(data: &[f32], mut h: u64) -> u64 {
+    const EDGE: usize = 4096; const WORDS: usize = 256;
+    let bytes = unsafe { std::slice::from_raw_parts(data.as_ptr() as *const u8, data.len() * 4) };
+    if bytes.len() <= 2 * EDGE + 8 * WORDS { return content_hash(bytes, h); }
+    h = content_hash(&bytes[..EDGE], h);
+    h = content_hash(&bytes[bytes.len() - EDGE..], h);
+    let step = ((bytes.len() - 2 * EDGE) / WORDS) & !7usize;
+    for i in 0..WORDS {
+        let o = EDGE + i * step;
+        h = (h ^ u64::from_ne_bytes(bytes[o..o + 8].try_into().unwrap())).wrapping_mul(0x100000001b3);
+        h ^= h >> 29;
+    }
+    h
+}
 
-/// Runs `f` with the device image of (quantizers, projection) while the cache lock is held, so the
-/// handle cannot be evicted under the call.  `None` => no device / creation failed => CPU path.
-fn with_codebook<R>(q: ArrayView3<f32>, p: Option<ArrayView2<f32>>, f: impl FnOnce(*mut pqhip_codebook) -> R) -> Option<R> {
+/// Pinned device image of (quantizers, projection).  `None` => no device / creation failed => CPU path.
+/// The cache lock is NOT held when this returns: run the GPU call on `pin.0`, then drop the pin.
+fn codebook(q: ArrayView3<f32>, p: Option<ArrayView2<f32>>) -> Option<Arc<Image>> {
     // contiguous copies only when the views are not in standard layout; the KEY uses the caller's pointers
     let key_q = q.as_ptr() as usize;
     let key_p = p.as_ref().map_or(0, |p| p.as_ptr() as usize);
@@ -111,29 +137,53 @@ fn with_codebook<R>(q: ArrayView3<f32>, p: Option<ArrayView2<f32>>, f: impl FnOn
     let ps = p.as_ref().map(|p| p.as_standard_layout());
     let (m, k, dsub) = qs.dim();
     let key = Key { q: key_q, q_len: qs.len(), p: key_p, m, k, dsub };
-    let mut hash = content_hash(qs.as_slice()?, 0xcbf29ce484222325);
-    if let Some(ps) = &ps { hash = content_hash(ps.as_slice()?, hash); }
-    let mut h = handles()?.lock().ok()?;
-    if let Some(i) = h.books.iter().position(|e| e.key == key) {
-        if h.books[i].hash == hash {
-            let e = h.books.remove(i);
-            h.books.insert(0, e);
-            return Some(f(h.books[0].cb));
+    let mut hash = sampled_hash(qs.as_slice()?, 0xcbf29ce484222325);
+    if let Some(ps) = &ps { hash = sampled_hash(ps.as_slice()?, hash); }
+    let h = handles()?;
+    let gen = h.generation.load(Ordering::Acquire);
+    let stale;                                           // dropped (=> destroyed) after the lock is released
+    {
+        let mut books = h.books.lock().ok()?;
+        match books.iter().position(|e| e.key == key) {
+            Some(i) if books[i].hash == hash && books[i].gen == gen => {
+                let e = books.remove(i);
+                let pin = e.image.clone();
+                books.insert(0, e);
+                return Some(pin);
+            }
+            Some(i) => stale = Some(books.remove(i)),     // same address, other contents or trained since
+            None => stale = None,
         }
-        let stale = h.books.remove(i);                 // same address, other contents
-        unsafe { pqhip_codebook_destroy(stale.cb) };
     }
+    drop(stale);
+    // the device image is built with the lock RELEASED
     let mut cb = std::ptr::null_mut();
-    let rc = unsafe { pqhip_codebook_create(h.ctx, qs.as_ptr(), m as i64, k as i64, dsub as i64,
+    let rc = unsafe { pqhip_codebook_create(h.ctx.0, qs.as_ptr(), m as i64, k as i64, dsub as i64,
         ps.as_ref().map_or(std::ptr::null(), |p| p.as_ptr()), &mut cb) };
     if rc != PQHIP_OK { return None; }
-    h.books.insert(0, Entry { key, hash, cb });
-    while h.books.len() > CACHE_CAP {
-        let old = h.books.pop().unwrap();
-        unsafe { pqhip_codebook_destroy(old.cb) };
+    let fresh = Arc::new(Image(cb));
+    let mut dropped = Vec::new();                        // evicted entries die outside the lock too
+    {
+        let mut books = h.books.lock().ok()?;
+        if let Some(i) = books.iter().position(|e| e.key == key) {
+            if books[i].hash == hash && books[i].gen == gen { return Some(books[i].image.clone()); }   // built twice: keep theirs
+            dropped.push(books.remove(i));
+        }
+        books.insert(0, Entry { key, hash, gen, image: fresh.clone() });
+        while books.len() > CACHE_CAP { dropped.push(books.pop().unwrap()); }
     }
-    Some(f(cb))
+    drop(dropped);
+    Some(fresh)
 }
+
+/// Runs `f` on the pinned device image; no lock is held while `f` (the GPU call) runs.
+fn with_codebook<R>(q: ArrayView3<f32>, p: Option<ArrayView2<f32>>, f: impl FnOnce(*mut pqhip_codebook) -> R) -> Option<R> {
+    let pin = codebook(q, p)?;
+    Some(f(pin.0))
+}
+
+/// Every entry point that rewrites quantizers or projections in place calls this.
+fn invalidate_images() { if let Some(h) = handles() { h.generation.fetch_add(1, Ordering::AcqRel); } }
 
 fn same<A: 'static, B: 'static>() -> bool { TypeId::of::<A>() == TypeId::of::<B>() }
 
@@ -218,15 +268,16 @@ pub fn try_kmeans_iterations<A, S>(mut quantizers: ArrayViewMut3<A>, instances: 
 where A: 'static + Copy, S: Data<Elem = A>,
 {
     if !same::<A, f32>() || instances.nrows() < MIN_GPU_ROWS || !quantizers.is_standard_layout() { return false; }
-    let h = match handles() { Some(h) => h.lock().unwrap(), None => return false };
+    let h = match handles() { Some(h) => h, None => return false };      // (no cache lock: serving calls keep running)
     let (m, k, dsub) = quantizers.dim();
     if instances.ncols() != m * dsub { return false; }          // the caller's asserts fire on the CPU path
     let xs = instances.strides();
     if xs.iter().any(|&s| s < 0) { return false; }
     let loss_ptr = match losses { Some(l) if l.len() == m => l.as_mut_ptr() as *mut f32, Some(_) => return false, None => std::ptr::null_mut() };
-    let rc = unsafe { pqhip_kmeans_iterations_f32(h.ctx, quantizers.as_mut_ptr() as *mut f32, m as i64, k as i64,
+    let rc = unsafe { pqhip_kmeans_iterations_f32(h.ctx.0, quantizers.as_mut_ptr() as *mut f32, m as i64, k as i64,
         dsub as i64, instances.as_ptr() as *const f32, instances.nrows() as i64, xs[0] as i64, xs[1] as i64,
         n_iterations as i32, loss_ptr) };
+    invalidate_images();                                   // the centroids were rewritten in place
     rc == PQHIP_OK
 }
 
@@ -236,24 +287,25 @@ where A: 'static + Copy, S: Data<Elem = A>,
 pub struct ResidentInstances { m: *mut pqhip_matrix, rows: usize, cols: usize }
 impl ResidentInstances {
     pub fn upload<S: Data<Elem = f32>>(x: &ArrayBase<S, Ix2>) -> Option<Self> {
-        let h = handles()?.lock().unwrap();
+        let h = handles()?;
         let (xs, mut m) = (x.strides(), std::ptr::null_mut());
         if xs.iter().any(|&s| s < 0) { return None; }
-        let rc = unsafe { pqhip_matrix_upload_f32(h.ctx, 0, x.as_ptr(), x.nrows() as i64, x.ncols() as i64,
+        let rc = unsafe { pqhip_matrix_upload_f32(h.ctx.0, 0, x.as_ptr(), x.nrows() as i64, x.ncols() as i64,
             xs[0] as i64, xs[1] as i64, &mut m) };
         if rc == PQHIP_OK { Some(Self { m, rows: x.nrows(), cols: x.ncols() }) } else { None }
     }
     /// In `Opq::train_iteration`: `if let Some(cross) = resident.train_step(projection.view(), centroids.view_mut())
     /// { let (u, _, vt) = cross.svd(true, true).unwrap(); projection.assign(&u.unwrap().dot(&vt.unwrap())); return; }`
     pub fn train_step(&self, projection: ArrayView2<f32>, mut quantizers: ArrayViewMut3<f32>) -> Option<ndarray::Array2<f32>> {
-        let h = handles()?.lock().unwrap();
+        let h = handles()?;                                // (no cache lock: a training step never blocks serving calls)
         let (m, k, dsub) = quantizers.dim();
         if m * dsub != self.cols || !quantizers.is_standard_layout() { return None; }
         let p = projection.as_standard_layout();
         let mut cross = ndarray::Array2::<f32>::zeros((self.cols, self.cols));
-        let rc = unsafe { pqhip_opq_train_step_f32_dev(h.ctx, 0, quantizers.as_mut_ptr(), m as i64, k as i64, dsub as i64,
+        let rc = unsafe { pqhip_opq_train_step_f32_dev(h.ctx.0, 0, quantizers.as_mut_ptr(), m as i64, k as i64, dsub as i64,
             p.as_ptr(), pqhip_matrix_device_ptr(self.m), self.rows as i64, self.cols as i64, cross.as_mut_ptr(),
             std::ptr::null_mut()) };
+        invalidate_images();                               // the quantizers were rewritten in place
         if rc == PQHIP_OK { Some(cross) } else { None }
     }
 }

@@ -6,6 +6,7 @@
 // around them).  Test infrastructure only -- the product never links this.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -57,6 +58,18 @@ hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t
     return hipSuccess;
 }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+// page-locking of caller memory (the zero-copy input leg): every third request is refused, so that both the
+// registered leg and its fall-back to the packing path run under the sanitizers; the byte range is touched so that a
+// span that overruns the caller's buffer is an ASan report
+static std::atomic<unsigned> g_reg_calls{0};
+hipError_t hipHostRegister(void* p, size_t n, unsigned)
+{
+    if (g_reg_calls.fetch_add(1) % 3 == 2) return hipErrorInvalidValue;
+    volatile const char* c = (volatile const char*)p;
+    if (n) { (void)c[0]; (void)c[n - 1]; }
+    return hipSuccess;
+}
+hipError_t hipHostUnregister(void*) { return hipSuccess; }
 
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 1; return hipSuccess; }

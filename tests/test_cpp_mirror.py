@@ -38,18 +38,21 @@ def _build_cache_test(tmp_path):
     import reductive_amd
     if not os.path.exists(reductive_amd.lib_path()):
         reductive_amd.build()
+    from oracle import pq_oracle
+    pq_oracle.build()                             # the checker of the concurrent-callers section (test infrastructure)
     exe = str(tmp_path / "test_codebook_cache")
-    libdir = os.path.join(ROOT, "reductive_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+    libdir, odir = os.path.join(ROOT, "reductive_amd"), os.path.join(ROOT, "oracle")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "test_codebook_cache.cpp"),
-                           "-L", libdir, "-lpqhip", "-Wl,-rpath," + libdir,
+                           "-L", libdir, "-lpqhip", "-Wl,-rpath," + libdir, "-L", odir, "-lpq_oracle", "-Wl,-rpath," + odir,
                            "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
     return exe
 
 
 def test_codebook_cache_policy(tmp_path):
     """The device-codebook cache of the reference-side binding (rust/pqhip_ffi.rs mirrors
-    include/reductive_amd/codebook_cache.hpp): content-validated hits, stale images replaced, bounded."""
+    include/reductive_amd/codebook_cache.hpp): validated hits, stale images replaced, bounded, entries pinned
+    while a call runs, generation bumped by the training entry points."""
     out = subprocess.run([_build_cache_test(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "cache policy checks passed" in out.stdout
@@ -57,6 +60,7 @@ def test_codebook_cache_policy(tmp_path):
 
 @pytest.mark.gpu
 def test_codebook_cache_never_serves_a_stale_device_image(tmp_path):
+    """... and 4 host threads x 2 quantizers through one cache overlap (wall < 0.7 x serial) with oracle-equal codes."""
     out = subprocess.run([_build_cache_test(tmp_path), "gpu"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all checks passed (GPU)" in out.stdout
