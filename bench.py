@@ -71,6 +71,8 @@ def parse():
                     help="torch.distributed backend for the barrier / max-reduction (gloo: rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank / slot uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--record-bytes", type=int, default=None, help="lookup workload: interleaved records of this many bytes (codes + scale of a row together) instead of a code matrix and a scale vector")
+    ap.add_argument("--lookup-codes", type=int, default=10_000_000, help="lookup workload: rows of the resident code matrix")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise sharding/reduction/printing only (CPU, gloo); no GPU work")
     return ap.parse_args()
@@ -176,12 +178,17 @@ class Bench:
             step = lambda: pq.reconstruct_batch_device(src, out=dst, check=False)
             kernel = "k_reconstruct" if workload == "reconstruct" else "k_reconstruct + k_rotate_pblock6 (x P^T)"
         elif workload == "lookup":
-            n_codes = 10_000_000
+            n_codes = args.lookup_codes
             src = torch.randint(0, k, (n_codes, m), device=self.dev, dtype=torch.uint8, generator=g)
             sel = torch.randint(0, n_codes, (rows,), device=self.dev, dtype=torch.int64, generator=g)
             scl = torch.rand((n_codes,), device=self.dev, dtype=torch.float32, generator=g) + 0.5
             dst = torch.empty((rows, d), device=self.dev, dtype=torch.float32)
-            step = lambda: pq.reconstruct_rows_device(src, sel, scales=scl, out=dst, check=False)
+            if not args.record_bytes:
+                step = lambda: pq.reconstruct_rows_device(src, sel, scales=scl, out=dst, check=False)
+            else:                                 # interleaved records: codes + scale of a row share one line (A/B: tools/lookup_ab.sh)
+                rec, rec_off = self.ra.Pq.interleave_records(src, scl, record_bytes=args.record_bytes)
+                step = lambda: pq.reconstruct_records_device(rec, rec_off, sel, out=dst, check=False)
+                extra["layout"] = "interleaved %d-byte records (codes at 0, f32 scale at %d)" % (rec.shape[1], rec_off)
             kernel = "k_reconstruct<.., SEL>"
         elif workload == "adc_scan":
             src = torch.randint(0, k, (rows, m), device=self.dev, dtype=torch.uint8, generator=g)

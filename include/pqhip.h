@@ -130,6 +130,20 @@ int32_t pqhip_reconstruct_rows_f32_dev(pqhip_codebook *cb, int32_t device_slot, 
                                        float *d_out, int64_t out_row_stride, void *stream);
 
 /*
+ * The same lookup over INTERLEAVED records: a resident matrix of n_codes records of `record_bytes` bytes, each
+ * holding the M codes of a row at offset 0 and its f32 scale at `scale_offset_bytes` (both multiples of 4 bytes;
+ * `record_bytes` also a multiple of `code_bytes`).  With 32-byte records at M = 15 (15 code bytes, 1 pad, the scale
+ * at offset 16, 12 pad) a lookup touches ONE 128-byte line where the split layout above touches one for the 15-byte
+ * code row (12 % of which straddle two) and one for the scale -- the resident-matrix layout of
+ * reductive_amd.qmatrix.QuantizedMatrix(interleave=True).  Semantics and results are those of
+ * pqhip_reconstruct_rows_f32_dev with d_scales given.
+ */
+int32_t pqhip_reconstruct_rows_records_f32_dev(pqhip_codebook *cb, int32_t device_slot, const void *d_records,
+                                               int32_t code_bytes, int64_t n_codes, int64_t record_bytes,
+                                               int64_t scale_offset_bytes, const int64_t *d_rows, int64_t n_rows,
+                                               float *d_out, int64_t out_row_stride, void *stream);
+
+/*
  * "Next" row: asymmetric distance computation -- the scan that follows
  * encode in a PQ pipeline, over a code matrix kept resident in HBM.  Not a function of reductive; it
  * is defined from the reference's own vector-to-matrix distance so that it has an exact meaning:

@@ -86,6 +86,8 @@ def lib():
     L.pqhip_reconstruct_batch_f32_dev.argtypes = [vp, i32, vp, i32, i64, i64, vp, i64, vp]
     L.pqhip_reconstruct_rows_f32_dev.restype = i32
     L.pqhip_reconstruct_rows_f32_dev.argtypes = [vp, i32, vp, i32, i64, i64, vp, i64, vp, vp, i64, vp]
+    L.pqhip_reconstruct_rows_records_f32_dev.restype = i32
+    L.pqhip_reconstruct_rows_records_f32_dev.argtypes = [vp, i32, vp, i32, i64, i64, i64, vp, i64, vp, i64, vp]
     L.pqhip_adc_tables_f32_dev.restype = i32
     L.pqhip_adc_tables_f32_dev.argtypes = [vp, i32, vp, i64, i64, vp, vp]
     L.pqhip_adc_scan_f32_dev.restype = i32
@@ -130,7 +132,7 @@ EXPORTS = [
     "pqhip_codebook_destroy", "pqhip_codebook_quantized_len",
     "pqhip_codebook_reconstructed_len", "pqhip_codebook_n_centroids",
     "pqhip_codebook_has_projection", "pqhip_quantize_batch_f32", "pqhip_reconstruct_batch_f32",
-    "pqhip_quantize_batch_f32_dev", "pqhip_reconstruct_batch_f32_dev", "pqhip_reconstruct_rows_f32_dev", "pqhip_check_codes_dev",
+    "pqhip_quantize_batch_f32_dev", "pqhip_reconstruct_batch_f32_dev", "pqhip_reconstruct_rows_f32_dev", "pqhip_reconstruct_rows_records_f32_dev", "pqhip_check_codes_dev",
     "pqhip_adc_tables_f32_dev", "pqhip_adc_scan_f32_dev",
     "pqhip_cluster_assignments_f32", "pqhip_kmeans_iterations_f32", "pqhip_kmeans_iterations_f32_dev",
     "pqhip_opq_train_step_f32_dev", "pqhip_at_dot_b_f32_dev", "pqhip_rotate_f32_dev",

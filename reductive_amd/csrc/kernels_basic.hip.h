@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
                                                      unsigned inv_cpr, int* __restrict__ err,
                                                      const int64_t* __restrict__ sel_rows = nullptr,
                                                      int64_t n_codes = 0,
-                                                     const float* __restrict__ sel_scales = nullptr)
+                                                     const float* __restrict__ sel_scales = nullptr,
+                                                     int64_t s_rs = 1 /* floats between the scales of consecutive code rows */)
 {
     // LDS: chunk -> (m, e) table, then the codes of the current and of the next row block.
     // The codes are the only operand that comes from HBM with a dependent use (code -> gather ->
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
         if (SEL && sel_scales && (int)threadIdx.x < rows) {
             int64_t src = sel_rows[row0 + threadIdx.x];
             if (src < 0 || src >= n_codes) src = 0;
-            pre_scale = sel_scales[src];
+            pre_scale = sel_scales[src * s_rs];
         }
     };
     auto stash_codes = [&](int buf) {
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void k_reconstruct_any(const IdxT* __restrict_
                                                          int M, int K, int dsub, int* __restrict__ err,
                                                          const int64_t* __restrict__ sel_rows,
                                                          int64_t n_codes,
-                                                         const float* __restrict__ sel_scales)
+                                                         const float* __restrict__ sel_scales, int64_t s_rs)
 {
     const int64_t d = (int64_t)M * dsub;
     const int64_t total = n * d;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void k_reconstruct_any(const IdxT* __restrict_
         uint64_t code = (uint64_t)codes[src * c_rs + m];
         if (code >= (uint64_t)K) { bad = true; code = 0; }
         float v = cb[((int64_t)m * K + (int64_t)code) * dsub + e];
-        if (sel_rows && sel_scales) v = fmul(v, sel_scales[src]);
+        if (sel_rows && sel_scales) v = fmul(v, sel_scales[src * s_rs]);
         out[row * o_rs + c] = v;
     }
     if (bad) atomicOr(err, 1);
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void k_reconstruct_any(const IdxT* __restrict_
 // out[row][0..d) *= scales[sel_rows[row]]  (lookup form with a projection: the scale follows the un-rotation)
 __global__ __launch_bounds__(256) void k_scale_rows(float* __restrict__ out, int64_t n, int d, int64_t o_rs,
                                                     const int64_t* __restrict__ sel_rows, int64_t n_codes,
-                                                    const float* __restrict__ sel_scales)
+                                                    const float* __restrict__ sel_scales, int64_t s_rs)
 {
     const int64_t total = n * d;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_scale_rows(float* __restrict__ out, int
         const int c = (int)(idx - row * d);
         int64_t src = sel_rows[row];
         if (src < 0 || src >= n_codes) src = 0;
-        out[row * o_rs + c] = fmul(out[row * o_rs + c], sel_scales[src]);
+        out[row * o_rs + c] = fmul(out[row * o_rs + c], sel_scales[src * s_rs]);
     }
 }
 

@@ -1179,7 +1179,7 @@ int cus_of(pqhip_codebook* cb, int slot) { return cb->ctx->devs[slot]->n_cus; }
 
 int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes, int64_t n,
                    int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st, int* err,
-                   const int64_t* sel_rows = nullptr, int64_t n_codes = 0, const float* sel_scales = nullptr)
+                   const int64_t* sel_rows = nullptr, int64_t n_codes = 0, const float* sel_scales = nullptr, int64_t s_rs = 1)
 {
     if (n == 0) return PQHIP_OK;
     CodebookDev& cd = cb->dev[slot];
@@ -1202,10 +1202,10 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
         const unsigned g = (unsigned)std::min<int64_t>((n * d + 255) / 256, 256 * 32);
         if (code_bytes == 1)
             hipLaunchKernelGGL((k_reconstruct_any<uint8_t>), dim3(g), dim3(256), 0, st, (const uint8_t*)d_codes, n, c_rs,
-                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, err, sel_rows, n_codes, sel_scales);
+                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, err, sel_rows, n_codes, sel_scales, s_rs);
         else if (code_bytes == 4)
             hipLaunchKernelGGL((k_reconstruct_any<uint32_t>), dim3(g), dim3(256), 0, st, (const uint32_t*)d_codes, n, c_rs,
-                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, err, sel_rows, n_codes, sel_scales);
+                               d_out, o_rs, cd.cb, (int)cb->M, (int)cb->K, (int)cb->dsub, err, sel_rows, n_codes, sel_scales, s_rs);
         else
             return PQHIP_EUNSUPPORTED;
         HIPCHK(hipGetLastError());
@@ -1235,12 +1235,12 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
             hipLaunchKernelGGL((k_reconstruct<IDX, V, true, GG, NEE>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
                                (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
-                               sel_rows, n_codes, sel_scales);                                    \
+                               sel_rows, n_codes, sel_scales, s_rs);                              \
         else                                                                                      \
             hipLaunchKernelGGL((k_reconstruct<IDX, V, false, GG, NEE>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
                                (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
-                               (const int64_t*)nullptr, (int64_t)0, (const float*)nullptr);       \
+                               (const int64_t*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)1); \
     } while (0)
 #define LAUNCH_REC2(IDX, V, GG)                                                                   \
     do {                                                                                          \
@@ -1360,12 +1360,12 @@ int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_
 int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes,
                              int64_t n, int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st,
                              const int64_t* sel_rows = nullptr, int64_t n_codes = 0,
-                             const float* sel_scales = nullptr)
+                             const float* sel_scales = nullptr, int64_t s_rs = 1)
 {
     if (n == 0) return PQHIP_OK;
     int* err = err_flag_for(cb, slot, st);
     if (!cb->has_proj)
-        return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st, err, sel_rows, n_codes, sel_scales);
+        return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st, err, sel_rows, n_codes, sel_scales, s_rs);
     // OPQ (pq.rs:323-326): gather into a leased scratch buffer, then out = r.dot(P^T); a lookup's scale comes last
     CodebookDev& cd = cb->dev[slot];
     const int64_t chunk = opq_chunk_rows(cb, slot, n);
@@ -1382,7 +1382,7 @@ int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, 
         if (sel_rows && sel_scales) {
             const unsigned g = (unsigned)std::min<int64_t>((rows * cb->d + 255) / 256, 256 * 32);
             hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, st, d_out + r0 * o_rs, rows, (int)cb->d, o_rs,
-                               sel_rows + r0, n_codes, sel_scales);
+                               sel_rows + r0, n_codes, sel_scales, s_rs);
             HIPCHK(hipGetLastError());
         }
     }
@@ -1670,6 +1670,27 @@ int32_t pqhip_reconstruct_rows_f32_dev(pqhip_codebook* cb, int32_t slot, const v
     SET_DEVICE(cb->ctx->devs[slot]->ordinal);
     return reconstruct_dev_impl(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, (hipStream_t)stream,
                                 d_rows, n_codes, d_scales);
+}
+
+int32_t pqhip_reconstruct_rows_records_f32_dev(pqhip_codebook* cb, int32_t slot, const void* d_records, int32_t code_bytes,
+                                               int64_t n_codes, int64_t record_bytes, int64_t scale_offset_bytes,
+                                               const int64_t* d_rows, int64_t n, float* d_out, int64_t o_rs, void* stream)
+{
+    if (!cb || n < 0 || n_codes < 0) return PQHIP_EINVAL;
+    if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
+    if (n > 0 && (!d_records || !d_out || !d_rows)) return PQHIP_EINVAL;
+    if (code_bytes != 1 && code_bytes != 4) return PQHIP_EUNSUPPORTED;
+    // a record = M codes, padding, one f32 scale, padding: whole code elements and whole floats per record
+    if (record_bytes <= 0 || record_bytes % 4 != 0 || record_bytes % code_bytes != 0 || scale_offset_bytes % 4 != 0 ||
+        scale_offset_bytes < cb->M * code_bytes || scale_offset_bytes + 4 > record_bytes || (reinterpret_cast<uintptr_t>(d_records) & 3))
+        return PQHIP_ESHAPE;
+    if (n > 0 && o_rs < cb->d) return PQHIP_ESHAPE;
+    if (n == 0) return PQHIP_OK;
+    if (n_codes == 0) return PQHIP_ECODE_RANGE;
+    SET_DEVICE(cb->ctx->devs[slot]->ordinal);
+    const float* scales = reinterpret_cast<const float*>(static_cast<const char*>(d_records) + scale_offset_bytes);
+    return reconstruct_dev_impl(cb, slot, d_records, code_bytes, n, record_bytes / code_bytes, d_out, o_rs, (hipStream_t)stream,
+                                d_rows, n_codes, scales, record_bytes / 4);
 }
 
 // ---- "next" row: asymmetric distance computation over a resident code matrix ----------------------

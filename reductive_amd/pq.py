@@ -711,6 +711,55 @@ class Pq:
                 raise _lib.PqHipError(rc, "pqhip_check_codes_dev")
         return out
 
+    @staticmethod
+    def interleave_records(codes, scales, record_bytes=None):
+        """Resident-matrix layout with ONE cache line per lookup: CUDA uint8 [N, record_bytes] records holding the M code
+        bytes of a row at offset 0 and its f32 scale at the next multiple of 16 bytes (32-byte records at M = 15).
+        Returns (records, scale_offset_bytes)."""
+        import torch
+        assert codes.is_cuda and codes.dtype == torch.uint8 and codes.dim() == 2
+        assert scales.is_cuda and scales.dtype == torch.float32 and scales.shape == (codes.shape[0],)
+        m = codes.shape[1]
+        off = (m + 15) // 16 * 16
+        rb = record_bytes or max(32, 1 << (off + 4 - 1).bit_length())
+        assert rb % 4 == 0 and off + 4 <= rb
+        rec = torch.zeros((codes.shape[0], rb), dtype=torch.uint8, device=codes.device)
+        rec[:, :m] = codes
+        rec[:, off:off + 4] = scales.contiguous().view(torch.uint8).view(-1, 4)
+        return rec, off
+
+    def reconstruct_records_device(self, records, scale_offset, rows, out=None, stream=None, check=True):
+        """reconstruct_rows_device over interleaved records (see interleave_records): same results, one 128-byte
+        line per lookup instead of two (pqhip_reconstruct_rows_records_f32_dev)."""
+        import torch
+        assert records.is_cuda and records.dtype == torch.uint8 and records.dim() == 2 and records.is_contiguous()
+        assert rows.is_cuda and rows.dtype == torch.int64 and rows.dim() == 1 and rows.is_contiguous()
+        n = rows.shape[0]
+        if out is None:
+            out = torch.empty((n, self.reconstructed_len()), dtype=torch.float32, device=records.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.stride(1) == 1
+        if tuple(out.shape) != (n, self.reconstructed_len()):
+            raise PanicError("Reconstructions matrix has incorrect shape, expected: (%d, %d), got: (%d, %d)"
+                             % (n, self.reconstructed_len(), out.shape[0], out.shape[1]))
+        cb = self._cb()
+        if stream is None:
+            stream = torch.cuda.current_stream(records.device).cuda_stream
+        slot = self._slot_for(records)
+        rc = _lib.lib().pqhip_reconstruct_rows_records_f32_dev(
+            cb, slot, records.data_ptr(), 1, records.shape[0], records.shape[1], scale_offset, rows.data_ptr(), n,
+            out.data_ptr(), out.stride(0) if n > 1 else max(out.stride(0), out.shape[1]), ctypes.c_void_p(stream))
+        if rc == _lib.ECODE_RANGE:
+            raise PanicError("ndarray: index out of bounds")
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_reconstruct_rows_records_f32_dev")
+        if check:
+            rc = _lib.lib().pqhip_check_codes_dev(cb, slot, ctypes.c_void_p(stream))
+            if rc == _lib.ECODE_RANGE:
+                raise PanicError("ndarray: index out of bounds")
+            if rc != _lib.OK:
+                raise _lib.PqHipError(rc, "pqhip_check_codes_dev")
+        return out
+
     # ---- "next" row (SURVEY.md 8f rank 4): asymmetric distance computation over resident codes -----
     def adc_tables_device(self, queries, stream=None):
         """queries: CUDA float32 [d] or [nq, d] -> tables [M, K] or [nq, M, K] with

@@ -962,6 +962,13 @@ def test_lookup_rows_matches_select_reconstruct_scale(ra, shape):
     with pytest.raises(ra.PanicError):
         pq.reconstruct_rows_device(tc, bad, scales=ts, check=True)
     assert pq.reconstruct_rows_device(tc, tr[:0]).shape == (0, d)
+    # interleaved records (codes + scale of a row in one 32/64-byte record: one line per lookup): same bits
+    if K <= 256:
+        rec, off = ra.Pq.interleave_records(tc, ts)
+        got_r = pq.reconstruct_records_device(rec, off, tr, check=True).cpu().numpy()
+        assert got_r.tobytes() == got_s.tobytes()
+        with pytest.raises(ra.PanicError):
+            pq.reconstruct_records_device(rec, off, bad, check=True)
 
 
 # ---- "next" row: the OPQ training iteration without its LAPACK calls (opq.rs:156-195) ------------
