@@ -71,6 +71,7 @@ def parse():
                     help="torch.distributed backend for the barrier / max-reduction (gloo: rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank / slot uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--queries", type=int, default=1, help="adc_scan workload: queries scanned per step (8 share one pass over the codes)")
     ap.add_argument("--record-bytes", type=int, default=None, help="lookup workload: interleaved records of this many bytes (codes + scale of a row together) instead of a code matrix and a scale vector")
     ap.add_argument("--lookup-codes", type=int, default=10_000_000, help="lookup workload: rows of the resident code matrix")
     ap.add_argument("--dry-run", action="store_true",
@@ -192,9 +193,11 @@ class Bench:
             kernel = "k_reconstruct<.., SEL>"
         elif workload == "adc_scan":
             src = torch.randint(0, k, (rows, m), device=self.dev, dtype=torch.uint8, generator=g)
-            query = torch.from_numpy(synth.normalish(45, (d,))).to(self.dev)
-            dst = torch.empty((rows,), device=self.dev, dtype=torch.float32)
+            nq = max(1, args.queries)
+            query = torch.from_numpy(synth.normalish(45, (d,) if nq == 1 else (nq, d))).to(self.dev)
+            dst = torch.empty((rows,) if nq == 1 else (nq, rows), device=self.dev, dtype=torch.float32)
             lut = pq.adc_tables_device(query)
+            extra["queries_per_scan"] = nq
             step = lambda: pq.adc_scan_device(src, lut, out=dst)
             kernel = "k_adc_scan"
         else:
@@ -246,7 +249,7 @@ class Bench:
             if workload == "lookup":
                 bytes_vec = 4 * d + m + 8 + 4     # output row + code row + row index + scale
             if workload == "adc_scan":
-                bytes_vec = m + 4                 # code row in, one f32 distance out
+                bytes_vec = m + 4 * max(1, args.queries)   # code row in, one f32 distance out per query
             ach = bytes_vec * rows / sec / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                     "traffic": traffic, "kernel": kernel, "avg_launch_ms": kernel_ms, "min_launch_ms": kmin,
@@ -606,8 +609,10 @@ def cpu_baseline_adc(q, query, src, dst, lut):
     """The oracle's table build + scan (declared f32 order: tables by CANON-F32 rules 1-3, row sums
     sequentially over m) on head and tail samples of the code matrix; GPU distances checked bit for bit."""
     from oracle import pq_oracle as orc
+    import numpy as np
     rows = src.shape[0]
-    n_s = min(2_000_000, rows)
+    nq = 1 if query.dim() == 1 else query.shape[0]
+    n_s = min(2_000_000 // nq, rows)
     qh = query.cpu().numpy()
     want_lut = orc.adc_tables(q, qh)
     ok = bool(lut.cpu().numpy().tobytes() == want_lut.tobytes())
@@ -618,9 +623,9 @@ def cpu_baseline_adc(q, query, src, dst, lut):
         want = orc.adc_scan(want_lut, c_host)
         t_cpu += time.perf_counter() - t
         n_tot += c_host.shape[0]
-        ok = ok and bool(dst[s0:s0 + n_s].cpu().numpy().tobytes() == want.tobytes())
+        ok = ok and bool(np.ascontiguousarray(dst[..., s0:s0 + n_s].cpu().numpy()).tobytes() == want.tobytes())
     return {"value": n_tot / t_cpu, "unit": "vectors/s", "cores": 1, "kind": "port",
-            "sample": "%d code rows (head and tail of the resident matrix), oracle scan on one thread (%.1f s)" % (n_tot, t_cpu),
+            "sample": "%d code rows x %d queries (head and tail of the resident matrix), oracle scan on one thread (%.1f s)" % (n_tot, nq, t_cpu),
             "gpu_distances_identical_on_sample": ok}
 
 

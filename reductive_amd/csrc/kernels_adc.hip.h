@@ -142,6 +142,100 @@ __global__ __launch_bounds__(256) void k_adc_scan_u8(const uint8_t* __restrict__
     if (bad) atomicOr(err, 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-query scan: one pass over the code matrix serves NQ queries (NQ = 4 or 8):
+//     out[q][i] = sum_{m in order, from +0} lut[q][m][codes[i][m]]          q = 0 .. NQ-1
+// The single-query kernel above re-reads the whole code matrix per query; here a row's M bytes are fetched once
+// and cost M + 4 NQ bytes of HBM traffic for NQ distances.  The NQ tables sit in LDS interleaved by query,
+// lut_s[half][m][code][4]: one ds_read_b128 brings a code's entries for four queries (entries 16 bytes apart: 16
+// distinct bank groups, like the 4-byte gathers of the single-query form), and the four sums advance with two packed
+// adds -- each query's sum is still its own sequential f32 chain over m, the declared order.  One 1,024-thread
+// workgroup per CU (the 8-query image is 120 KB of LDS at M = 15, K = 256), contiguous row range per workgroup.
+// ---------------------------------------------------------------------------------------------
+template <int NV, int NQ>
+__global__ __launch_bounds__(1024) void k_adc_scan_u8_mq(const uint8_t* __restrict__ codes, int64_t n, int64_t c_rs,
+                                                         const float* __restrict__ lut /* [NQ][M][K] */, int M, int K,
+                                                         float* __restrict__ out, int64_t o_rs, int64_t rows_per_wg,
+                                                         int* __restrict__ err)
+{
+    static_assert(NQ == 4 || NQ == 8, "queries per pass");
+    constexpr int NW = NV + 1, NH = NQ / 4;
+    extern __shared__ __attribute__((aligned(16))) float lutq_s[];   // [NH][M][K][4]
+    const int MK = M * K;
+    for (int i = threadIdx.x; i < NQ * MK; i += 1024) {
+        const int q = i / MK, r = i - q * MK;
+        lutq_s[((q >> 2) * MK + r) * 4 + (q & 3)] = lut[i];
+    }
+    __syncthreads();
+    const int64_t row_begin = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t row_end = row_begin + rows_per_wg;
+    if (row_end > n) row_end = n;
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(codes);
+    const uintptr_t hi = lo + (uintptr_t)((n - 1) * c_rs + M);      // one past the last code byte
+    bool bad = false;
+    for (int64_t row = row_begin + threadIdx.x; row < row_end; row += 1024) {
+        const uintptr_t a = lo + (uintptr_t)(row * c_rs);
+        const uintptr_t a0 = a & ~(uintptr_t)3;
+        unsigned w[NW];
+        if (a0 >= lo && a0 + 4 * NW <= hi) {
+            const unsigned* p = reinterpret_cast<const unsigned*>(a0);
+            constexpr int N4 = (NW / 4) * 4, N2 = N4 + ((NW - N4) / 2) * 2;
+#pragma unroll
+            for (int k = 0; k < N4; k += 4) {
+                const u32x4_u v = *reinterpret_cast<const u32x4_u*>(p + k);
+                w[k] = v[0]; w[k + 1] = v[1]; w[k + 2] = v[2]; w[k + 3] = v[3];
+            }
+            if (N2 > N4) {
+                const u32x2_u v = *reinterpret_cast<const u32x2_u*>(p + N4);
+                w[N4] = v[0]; w[N4 + 1] = v[1];
+            }
+            if (NW > N2) w[N2] = p[N2];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                unsigned v = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uintptr_t b = a0 + 4 * k + e;
+                    if (b >= a && b < a + (uintptr_t)M) v |= (unsigned)*reinterpret_cast<const uint8_t*>(b) << (8 * e);
+                }
+                w[k] = v;
+            }
+        }
+        const unsigned sh = (unsigned)(a & 3);
+        f32x2 s[NH][2];
+#pragma unroll
+        for (int hq = 0; hq < NH; ++hq) { s[hq][0] = (f32x2){0.f, 0.f}; s[hq][1] = (f32x2){0.f, 0.f}; }
+        const float* lm = lutq_s;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const unsigned v = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);   // bytes 4k .. 4k+3 of the row
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (4 * k + e < M) {
+                    unsigned c = (v >> (8 * e)) & 0xffu;
+                    if (c >= (unsigned)K) { bad = true; c = 0; }
+#pragma unroll
+                    for (int hq = 0; hq < NH; ++hq) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(lm + (size_t)hq * MK * 4 + 4 * c);
+                        s[hq][0] = pk_add(s[hq][0], (f32x2){t[0], t[1]});
+                        s[hq][1] = pk_add(s[hq][1], (f32x2){t[2], t[3]});
+                    }
+                    lm += 4 * K;
+                }
+            }
+        }
+#pragma unroll
+        for (int hq = 0; hq < NH; ++hq) {
+            out[(int64_t)(4 * hq + 0) * o_rs + row] = s[hq][0][0];
+            out[(int64_t)(4 * hq + 1) * o_rs + row] = s[hq][0][1];
+            out[(int64_t)(4 * hq + 2) * o_rs + row] = s[hq][1][0];
+            out[(int64_t)(4 * hq + 3) * o_rs + row] = s[hq][1][1];
+        }
+    }
+    if (bad) atomicOr(err, 1);
+}
+
 // any index width / any table size: tables read through L2, one thread per row.  No throughput claim.
 template <typename IdxT>
 __global__ __launch_bounds__(256) void k_adc_scan_any(const IdxT* __restrict__ codes, int64_t n, int64_t c_rs,

@@ -1479,6 +1479,24 @@ int32_t launch_adc_nv(int nv, const uint8_t* codes, int64_t n, int64_t c_rs, con
     }
 }
 
+template <int NV, int NQ>
+int32_t launch_adc_mq(int nv, const uint8_t* codes, int64_t n, int64_t c_rs, const float* lut, int M, int K, float* out,
+                      int64_t o_rs, int n_cus, size_t lds, int* err, hipStream_t st)
+{
+    if constexpr (NV > kAdcMaxValueWords) {
+        return PQHIP_EUNSUPPORTED;
+    } else {
+        if (nv != NV) return launch_adc_mq<NV + 1, NQ>(nv, codes, n, c_rs, lut, M, K, out, o_rs, n_cus, lds, err, st);
+        HIPCHK(hipFuncSetAttribute((const void*)k_adc_scan_u8_mq<NV, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        // one 1,024-thread workgroup per CU (the table image fills most of the LDS), one contiguous row range each
+        int64_t rows_per_wg = round_up((n + n_cus - 1) / n_cus, 1024);
+        rows_per_wg = std::max<int64_t>(rows_per_wg, 4096);
+        const unsigned grid = (unsigned)((n + rows_per_wg - 1) / rows_per_wg);
+        hipLaunchKernelGGL((k_adc_scan_u8_mq<NV, NQ>), dim3(grid), dim3(1024), lds, st, codes, n, c_rs, lut, M, K, out, o_rs, rows_per_wg, err);
+        return PQHIP_OK;
+    }
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1741,7 +1759,25 @@ int32_t pqhip_adc_scan_f32_dev(pqhip_codebook* cb, int32_t slot, const float* d_
     const size_t lds = (size_t)M * K * sizeof(float);
     const int nv = (M + 3) / 4;
     const bool fast = code_bytes == 1 && lds <= 160 * 1024 && nv <= kAdcMaxValueWords;
-    for (int64_t q = 0; q < nq; ++q) {
+    // several queries per pass over the code matrix: 8 (or 4) tables interleaved in LDS when they fit
+    // (PQHIP_DEBUG_ADC_SINGLE=1: one pass per query, the round-2 form, for A/B)
+    static const bool mq_on = getenv("PQHIP_DEBUG_ADC_SINGLE") == nullptr;
+    int64_t q = 0;
+    if (fast && mq_on) {
+        const int n_cus = cb->ctx->devs[slot]->n_cus;
+        for (int nqp : {8, 4}) {
+            const size_t lds_q = lds * nqp;
+            if (lds_q > 160 * 1024) continue;
+            for (; q + nqp <= nq; q += nqp) {
+                const float* lut = d_tables + q * (int64_t)M * K;
+                float* out = d_out + q * o_rs;
+                if (nqp == 8) PQCHK((launch_adc_mq<1, 8>(nv, (const uint8_t*)d_codes, n, c_rs, lut, M, K, out, o_rs, n_cus, lds_q, err, st)));
+                else PQCHK((launch_adc_mq<1, 4>(nv, (const uint8_t*)d_codes, n, c_rs, lut, M, K, out, o_rs, n_cus, lds_q, err, st)));
+                HIPCHK(hipGetLastError());
+            }
+        }
+    }
+    for (; q < nq; ++q) {
         const float* lut = d_tables + q * (int64_t)M * K;
         float* out = d_out + q * o_rs;
         if (fast) {

@@ -97,6 +97,35 @@ def test_gpu_tables_and_scan_match_oracle(ra, M, K, dsub, opq, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,K,dsub,n,nq", [(15, 256, 20, 70001, 8), (15, 256, 20, 5003, 13), (15, 256, 20, 1025, 4), (48, 256, 16, 9001, 9),
+                                           (3, 7, 5, 777, 21), (100, 64, 2, 3000, 8), (16, 16, 8, 100, 5), (96, 256, 8, 4100, 6)])
+def test_gpu_multi_query_scan_matches_oracle(ra, M, K, dsub, n, nq):
+    """several queries per pass over the resident codes (8 or 4 tables interleaved in LDS, the rest
+    one by one) -- every (query, row) distance equals the oracle's sequential f32 sum, whatever mix of passes serves nq
+    queries; strided / unaligned code rows and the range flag behave as in the single-query form."""
+    import torch
+    d = M * dsub
+    q = synth.normalish(9800 + d + K, (M, K, dsub))
+    pq = ra.Pq(None, q)
+    ys = synth.normalish(9801 + d + nq, (nq, d))
+    t = pq.adc_tables_device(torch.from_numpy(ys).cuda())
+    want_t = orc.adc_tables(q, ys)
+    assert t.cpu().numpy().tobytes() == want_t.tobytes()
+    wide = synth.codes_u8(9802 + d, (n + 3, M + 5), K)
+    wd = torch.from_numpy(wide).cuda()
+    for r0, c0 in ((0, 0), (1, 3), (3, 5)):                  # aligned and unaligned first rows, row stride M + 5
+        view = wd[r0:r0 + n, c0:c0 + M]
+        got = pq.adc_scan_device(view, t, check=True)
+        assert got.shape == (nq, n)
+        assert got.cpu().numpy().tobytes() == orc.adc_scan(want_t, np.ascontiguousarray(wide[r0:r0 + n, c0:c0 + M])).tobytes()
+    if K < 256:
+        bad = wd[:n, :M].contiguous()
+        bad[n - 1, M - 1] = K
+        with pytest.raises(ra.PanicError, match="index out of bounds"):
+            pq.adc_scan_device(bad, t, check=True)
+
+
+@pytest.mark.gpu
 def test_gpu_scan_unaligned_strided_and_range(ra):
     import torch
     M, K, dsub = 15, 100, 4
