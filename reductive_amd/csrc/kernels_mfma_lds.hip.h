@@ -20,6 +20,8 @@
 
 #ifndef ENC_ABLATE
 #define ENC_ABLATE 0      // timing experiments only (results are wrong): 1 no fold/store, 2 no keys/atomics/fold, 3 no atomics, 4 no x loads
+#elif ENC_ABLATE != 0 && !defined(PQHIP_TIMING_ONLY_BUILD)
+#error "ENC_ABLATE produces wrong results: only `make TIMING=1` (libpqhip_timing.so, -DPQHIP_TIMING_ONLY_BUILD) may set it"
 #endif
 
 namespace pqhip {

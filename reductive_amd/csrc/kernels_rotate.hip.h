@@ -6,6 +6,8 @@
 
 #ifndef ROT_ABLATE
 #define ROT_ABLATE 0      // timing experiments only (results wrong): 1 no global stores, 2 no epilogue at all, 3 no x fetch/stash, 4 no LDS operand reads after the first group
+#elif ROT_ABLATE != 0 && !defined(PQHIP_TIMING_ONLY_BUILD)
+#error "ROT_ABLATE produces wrong results: only `make TIMING=1` (libpqhip_timing.so, -DPQHIP_TIMING_ONLY_BUILD) may set it"
 #endif
 namespace pqhip {
 

@@ -9,11 +9,13 @@ none can be produced in this image (no Rust toolchain).  What is pinned is the i
 :103-105) and the round trip through our own writer.
 
 Storage chunk, little endian:
-    u32 chunk identifier (3 = quantized array)     u64 chunk length in bytes (of what follows)
+    u32 chunk identifier (4 = QuantizedArray; 3 is BucketSubwordVocab)     u64 chunk length in bytes (of what follows)
     u32 projection (0/1)   u32 norms (0/1)   u32 quantized_len M   u32 reconstructed_len d
     u32 n_centroids K      u64 n_embeddings N
     u32 quantized type id (1 = u8)   u32 reconstructed type id (10 = f32)
-    zero padding up to a multiple of 4 bytes from the start of the stream
+    zero padding up to a multiple of 4 bytes of the ABSOLUTE position in the file (the chunk follows the magic,
+    the header chunk and usually a vocabulary chunk, so its start is not aligned in general: writer and reader take the
+    position from f.tell(), or from `stream_offset` for streams that cannot tell)
     [d x d] f32 projection (if flagged)    [M x K x d/M] f32 quantizers
     [N] f32 norms (if flagged)             [N x M] u8 quantized embeddings
 """
@@ -24,7 +26,7 @@ import numpy as np
 
 from .pq import Pq, PanicError
 
-CHUNK_QUANTIZED_ARRAY = 3
+CHUNK_QUANTIZED_ARRAY = 4
 TYPE_U8, TYPE_F32 = 1, 10
 
 
@@ -32,8 +34,19 @@ class FormatError(ValueError):
     pass
 
 
-def write_chunk(f, pq, codes, norms=None, stream_offset=0):
-    """Serialise (pq, codes [N, M] u8, norms [N] f32 or None) as one storage chunk."""
+def _position(f, stream_offset):
+    """absolute position of the next byte of `f` in its file (f.tell() when the stream supports it)"""
+    if stream_offset is not None:
+        return stream_offset
+    try:
+        return f.tell()
+    except (OSError, AttributeError, io.UnsupportedOperation):
+        return 0
+
+
+def write_chunk(f, pq, codes, norms=None, stream_offset=None):
+    """Serialise (pq, codes [N, M] u8, norms [N] f32 or None) as one storage chunk at the stream's current position."""
+    stream_offset = _position(f, stream_offset)
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     M, K, dsub = pq.subquantizers().shape
     if codes.ndim != 2 or codes.shape[1] != M:
@@ -58,8 +71,10 @@ def write_chunk(f, pq, codes, norms=None, stream_offset=0):
     f.write(payload)
 
 
-def read_chunk(f, stream_offset=0, ctx=None):
-    """Parse one storage chunk -> (Pq, codes [N, M] u8, norms [N] f32 or None); host arrays."""
+def read_chunk(f, stream_offset=None, ctx=None):
+    """Parse the storage chunk that starts at the stream's current position -> (Pq, codes [N, M] u8, norms [N] f32 or
+    None); host arrays."""
+    stream_offset = _position(f, stream_offset)
     def take(n):
         b = f.read(n)
         if len(b) != n:

@@ -31,7 +31,7 @@ def test_chunk_round_trip_and_header(ra, opq, norms):
     nr = synth.uniform01(9803, (N,)) + np.float32(0.5) if norms else None
     blob = qmatrix.dumps(ra.Pq(P, q), codes, nr)
     ident, length = struct.unpack("<IQ", blob[:12])
-    assert ident == 3 and length == len(blob) - 12
+    assert ident == 4 and length == len(blob) - 12     # 4 = QuantizedArray in finalfusion's chunk identifiers
     assert struct.unpack("<IIIIIQII", blob[12:48]) == (int(opq), int(norms), M, d, K, N, 1, 10)
     assert len(blob) == 48 + (d * d * 4 if opq else 0) + M * K * dsub * 4 + (N * 4 if norms else 0) + N * M
     pq, c2, n2 = qmatrix.read_chunk(io.BytesIO(blob))
@@ -44,6 +44,17 @@ def test_chunk_round_trip_and_header(ra, opq, norms):
     b.seek(3)
     pq3, c3, _ = qmatrix.read_chunk(b, stream_offset=3)
     assert pq3 == pq and c3.tobytes() == codes.tobytes()
+    # a chunk in the middle of a file (behind magic / header / vocabulary bytes): the padding follows the ABSOLUTE
+    # position, which writer and reader take from the stream itself
+    for lead in (5, 6, 7, 8):
+        b = io.BytesIO()
+        b.write(b"v" * lead)
+        qmatrix.write_chunk(b, ra.Pq(P, q), codes, nr)
+        pad = (-(lead + 48)) % 4
+        assert len(b.getvalue()) == lead + len(blob) + pad
+        b.seek(lead)
+        pq4, c4, n4 = qmatrix.read_chunk(b)
+        assert pq4 == pq and c4.tobytes() == codes.tobytes() and (nr is None or n4.tobytes() == nr.tobytes())
 
 
 def test_malformed_chunks_are_refused(ra):
