@@ -28,6 +28,7 @@
 #include "kernels_rotate8.hip.h"
 #include "kernels_kmeans.hip.h"
 #include "kernels_adc.hip.h"
+#include "kernels_pair16.hip.h"
 #include "encode_launch.h"
 #include "opq_fused_launch.h"
 #include "smallk_launch.h"
@@ -241,6 +242,7 @@ struct CodebookDev {
     float* frags = nullptr;  // [M][T][S][64]
     float* cc = nullptr;     // [M][k_pad]
     float* cbt = nullptr;    // [M][dsub][KP] transposed image for the small-codebook kernel (K <= 64)
+    float* fragp = nullptr;  // [NP][dsub][64] block-diagonal pair fragments + [NP][2][16] norms (K <= 16: kernels_pair16.hip.h)
     float* P = nullptr;      // [d][d]   x.dot(P)
     float* PT = nullptr;     // [d][d]   r.dot(P^T)
     int* err = nullptr;      // [0] unused, [1] "some ||c||^2 not finite" (k_check_norms), [2 .. 2 + kErrSlots):
@@ -271,6 +273,7 @@ struct pqhip_codebook {
     // MFMA encode geometry (0 = shape not covered, anchor kernel is used)
     int T = 0, DP = 0, k_pad = 0;
     int KP = 0;             // small codebooks (K <= 64, instantiated dsub): padded centroid count of the VALU kernel
+    bool pair16 = false;    // K <= 16 and dsub in {2, 4, 8, 16}: the two-subquantizers-per-tile kernel applies
     int groups = 1;         // K > 256: groups of 256 centroids (8 tiles each) merged through 64-bit keys
     bool norms_ok = false;  // all ||c||^2 finite and < 2^100
     int variant = 0;        // 0 auto, 1 anchor, 2 mfma
@@ -506,6 +509,41 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     CodebookDev& cd = cb->dev[slot];
     if (cb->groups > 1 && cb->variant != 1 && cb->norms_ok && code_bytes == 4)
         return encode_grouped_dev(cb, slot, d_x, n, x_rs, d_codes, o_rs, st);
+    // K <= 16 with sub-vectors of 2 / 4 / 8 / 16 floats: one matrix tile serves two subquantizers, x is read once in whole
+    // lines (kernels_pair16.hip.h).  Variant 7 forces it; variants 1..6 keep the others.
+    // Measured (tools/smallk_ab.sh, one box, vectors/s pair / VALU kernel / default MFMA kernel): d=128 M=64 (dsub 2) 3.59e9 / 3.31e9 /
+    // 1.50e9; d=300 M=75 (dsub 4) 2.14e9 / 1.41e9 / 1.21e9; d=128 M=32 (dsub 4) 5.09e9 / 5.61e9 / 2.89e9; d=128 M=16 (dsub 8, the
+    // reference's bench shape) 5.95e9 / 6.69e9 / 4.76e9; d=768 M=48 (dsub 16) 1.14e9 / 0.70e9 / 1.18e9 -- the zero blocks double the
+    // matrix time, which the shared FP32 pipe charges in full, so auto takes it only where it wins: dsub 2, and dsub 4 with many
+    // subquantizers.
+    const bool pair_auto = cb->variant == 0 && (cb->dsub == 2 || (cb->dsub == 4 && cb->M >= 48));
+    if ((pair_auto || cb->variant == 7) && cb->pair16 && code_bytes == 1 && cb->norms_ok && bad_flag == nullptr) {
+        Pair16Args a;
+        const int NP = (int)((cb->M + 1) / 2);
+        a.x = d_x; a.n = n; a.x_rs = x_rs; a.out = (uint8_t*)d_codes; a.o_rs = o_rs;
+        a.fragp = cd.fragp; a.ccp = cd.fragp + (int64_t)NP * cb->dsub * 64; a.cb = cd.cb; a.cc = cd.cc;
+        a.M = (int)cb->M; a.K = (int)cb->K; a.k_pad = cb->k_pad; a.NP = NP;
+        a.n_tiles = (n + 31) / 32;
+        const size_t lds = ((size_t)NP * cb->dsub * 64 + (size_t)NP * 32 + 4 * 2 * 32 * 36) * sizeof(float);
+        const int per_cu = std::max<int>(1, std::min<int>(3, (int)(160 * 1024 / lds)));
+        const unsigned grid = (unsigned)std::min<int64_t>((a.n_tiles + 3) / 4, (int64_t)cb->ctx->devs[slot]->n_cus * per_cu);
+#define LAUNCH_P16(D)                                                                                                   \
+        do {                                                                                                            \
+            HIPCHK(hipFuncSetAttribute((const void*)k_encode_pair16<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            hipLaunchKernelGGL((k_encode_pair16<D>), dim3(grid), dim3(256), lds, st, a);                                 \
+        } while (0)
+        switch ((int)cb->dsub) {
+        case 2: LAUNCH_P16(2); break;
+        case 4: LAUNCH_P16(4); break;
+        case 8: LAUNCH_P16(8); break;
+        default: LAUNCH_P16(16); break;
+        }
+#undef LAUNCH_P16
+        HIPCHK(hipGetLastError());
+        cb->last_kernel = "k_encode_pair16";
+        return PQHIP_OK;
+    }
+    if (cb->variant == 7) return PQHIP_EUNSUPPORTED;
     // Small codebooks: the VALU kernel reads x once, in whole row segments, and keeps the centroids on the scalar
     // path (kernels_smallk.hip.h).  Auto choice for K <= 16 with sub-vectors of <= 8 floats -- the reference's
     // own bench shape, d = 128, M = 16, K = 16: 6.3e9 vectors/s against 4.4e9 for the MFMA kernel; for wider
@@ -802,6 +840,12 @@ int32_t prepare_codebook_dev(pqhip_codebook* cb, int slot, hipStream_t st, bool*
         hipLaunchKernelGGL(k_build_cbt, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cd.cb, (int)M, (int)K,
                            (int)dsub, cb->KP, cd.cbt);
     }
+    if (cb->pair16) {
+        const int NP = (int)((M + 1) / 2);
+        const int64_t total = (int64_t)NP * dsub * 64 + NP * 32;
+        hipLaunchKernelGGL(k_build_pair_frags, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cd.cb, cd.cc, (int)M, (int)K,
+                           (int)dsub, cb->k_pad, cd.fragp, cd.fragp + (int64_t)NP * dsub * 64);
+    }
     HIPCHK(hipGetLastError());
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, cd.err + 1, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -832,6 +876,12 @@ int32_t prepare_codebook_async(pqhip_codebook* cb, int slot, hipStream_t st)
         const int64_t tot = M * dsub * cb->KP;
         hipLaunchKernelGGL(k_build_cbt, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, cd.cb, (int)M, (int)K,
                            (int)dsub, cb->KP, cd.cbt);
+    }
+    if (cb->pair16) {
+        const int NP = (int)((M + 1) / 2);
+        const int64_t tot = (int64_t)NP * dsub * 64 + NP * 32;
+        hipLaunchKernelGGL(k_build_pair_frags, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, cd.cb, cd.cc, (int)M, (int)K,
+                           (int)dsub, cb->k_pad, cd.fragp, cd.fragp + (int64_t)NP * dsub * 64);
     }
     HIPCHK(hipGetLastError());
     return PQHIP_OK;
@@ -873,6 +923,11 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
     }
     cb->T = T; cb->DP = DP; cb->groups = groups;
     cb->KP = (T != 0 && smallk_has((int)dsub)) ? smallk_kp(K) : 0;
+    {   // pair kernel: K <= 16, power-of-two sub-vectors up to 16 floats, fragment image + slabs within 160 KB of LDS
+        const int64_t NP = (M + 1) / 2;
+        const size_t lds = ((size_t)NP * dsub * 64 + (size_t)NP * 32 + 4 * 2 * 32 * 36) * sizeof(float);
+        cb->pair16 = K <= 16 && (dsub == 2 || dsub == 4 || dsub == 8 || dsub == 16) && lds <= 160 * 1024;
+    }
     cb->k_pad = T ? T * 32 * groups : (int)round_up(K, 32);
     const int S = DP / 2;
 
@@ -899,6 +954,7 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
         HIPCHK(hipMemsetAsync(cd.err, 0, (2 + kErrSlots) * sizeof(int), st));
         if (T) HIPCHK(hipMalloc((void**)&cd.frags, (size_t)(M * groups * T * S * 64) * sizeof(float)));
         if (cb->KP) HIPCHK(hipMalloc((void**)&cd.cbt, (size_t)(M * dsub * cb->KP) * sizeof(float)));
+        if (cb->pair16) HIPCHK(hipMalloc((void**)&cd.fragp, (size_t)(((M + 1) / 2) * (dsub * 64 + 32)) * sizeof(float)));
         if (projection) {
             const size_t pb = (size_t)cb->d * cb->d * sizeof(float);
             HIPCHK(hipMalloc((void**)&cd.P, pb));
@@ -1616,6 +1672,7 @@ void pqhip_codebook_destroy(pqhip_codebook* cb)
         if (cd.frags) (void)hipFree(cd.frags);
         if (cd.cc) (void)hipFree(cd.cc);
         if (cd.cbt) (void)hipFree(cd.cbt);
+        if (cd.fragp) (void)hipFree(cd.fragp);
         if (cd.P) (void)hipFree(cd.P);
         if (cd.PT) (void)hipFree(cd.PT);
         if (cd.err) (void)hipFree(cd.err);
@@ -1634,7 +1691,7 @@ int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && c
 
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {
-    if (!cb || variant < 0 || variant > 6) return PQHIP_EINVAL;
+    if (!cb || variant < 0 || variant > 7) return PQHIP_EINVAL;
     cb->variant = variant;
     return PQHIP_OK;
 }

@@ -37,7 +37,10 @@ def test_every_instantiation_matches_oracle(ra, K, dsub):
     assert got.cpu().numpy().tobytes() == want.tobytes()
     auto = ra.Pq(None, q)
     assert auto.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy().tobytes() == want.tobytes()
-    assert (auto.last_encode_kernel() == "k_encode_smallk") == (K <= 16 and dsub <= 8)
+    # auto: K <= 16 with sub-vectors of 2 floats (or 4 floats and >= 48 subquantizers) -> the pair kernel; other K <= 16, dsub <= 8 -> this one
+    pair = K <= 16 and (dsub == 2 or (dsub == 4 and M >= 48))
+    assert (auto.last_encode_kernel() == "k_encode_pair16") == pair
+    assert (auto.last_encode_kernel() == "k_encode_smallk") == (K <= 16 and dsub <= 8 and not pair)
     pq4 = ra.Pq(None, q)
     pq4.set_encode_variant(4)        # the MFMA kernel on the same input
     got4 = pq4.quantize_batch_device(torch.from_numpy(x).cuda())
@@ -66,6 +69,10 @@ def test_reference_bench_shape_special_values_and_strides(ra):
     assert pq.last_encode_kernel() == "k_encode_smallk"
     assert got.tobytes() == want.tobytes()
     assert want[15, 3] == 2
+    pq7 = ra.Pq(None, q)
+    pq7.set_encode_variant(7)        # the pair kernel on the same special values (NaN / Inf reach both halves of a pair)
+    assert pq7.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy().tobytes() == want.tobytes()
+    assert pq7.last_encode_kernel() == "k_encode_pair16"
     # strided rows, 4-byte aligned only (row stride d + 3), codes into a wider matrix
     wide = torch.zeros((5000, d + 3), device="cuda")
     wide[:, :d] = torch.from_numpy(x[:5000]).cuda()
@@ -86,7 +93,7 @@ def test_non_finite_codebook_falls_back_and_stays_exact(ra):
     with np.errstate(all="ignore"):
         want = orc.quantize_batch(q, x, n_threads=4)
     got = pq.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy()
-    assert pq.last_encode_kernel() != "k_encode_smallk"
+    assert pq.last_encode_kernel() not in ("k_encode_smallk", "k_encode_pair16")
     assert got.tobytes() == want.tobytes()
 
 
@@ -99,3 +106,44 @@ def test_kmeans_assignment_uses_it_and_stays_bit_identical(ra):
     got_q, got_loss = ra.kmeans_iterations(q0, torch.from_numpy(x).cuda(), n_iterations=2)
     want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=2, n_threads=8)
     assert got_q.tobytes() == want_q.tobytes() and got_loss.tobytes() == want_loss.tobytes()
+
+
+@pytest.mark.parametrize("M,K,dsub,n", [(16, 16, 8, 70001), (15, 16, 8, 4097), (1, 16, 8, 333), (7, 5, 4, 10000), (33, 16, 2, 5001),
+                                        (48, 16, 16, 20000), (9, 1, 16, 64), (2, 13, 2, 31), (64, 16, 4, 3000), (5, 16, 16, 1)])
+def test_pair_kernel_two_subquantizers_per_tile(ra, M, K, dsub, n):
+    """kernels_pair16.hip.h (variant 7 / auto for K <= 16): odd M (the last pair is half empty), K < 16 (padding centroids),
+    every sub-vector length, row counts that are not multiples of 32, rows that coincide with centroids, NaN / Inf / huge
+    rows in both halves of a pair -- codes equal the oracle's."""
+    import torch
+    q = synth.normalish(7800 + M + K + dsub, (M, K, dsub))
+    x = synth.normalish(7900 + M + K + dsub, (n, M * dsub))
+    if n > 40:
+        x[3, 0] = np.nan                              # first sub-vector (half 0 of pair 0)
+        x[4, M * dsub - 1] = np.inf                   # last sub-vector
+        x[5] *= np.float32(1e19)                      # huge norms everywhere
+        x[6, :dsub] = q[0, K - 1]                     # a row that IS a centroid: distance 0 up to rounding
+        if M > 1:
+            x[7, dsub:2 * dsub] = q[1, 0]
+    pq = ra.Pq(None, q)
+    pq.set_encode_variant(7)
+    with np.errstate(all="ignore"):
+        want = orc.quantize_batch(q, x, n_threads=8)
+    xd = torch.from_numpy(x).cuda()
+    got = pq.quantize_batch_device(xd).cpu().numpy()
+    assert pq.last_encode_kernel() == "k_encode_pair16"
+    assert got.tobytes() == want.tobytes()
+    # strided rows (4-byte aligned only) and a wider code matrix
+    wide = torch.zeros((n, M * dsub + 3), device="cuda")
+    wide[:, :M * dsub] = xd
+    out = torch.full((n, M + 2), 255, device="cuda", dtype=torch.uint8)
+    pq.quantize_batch_device(wide[:, :M * dsub], out=out[:, :M])
+    assert out[:, :M].cpu().numpy().tobytes() == want.tobytes() and int((out[:, M:] != 255).sum()) == 0
+
+
+def test_pair_kernel_is_refused_outside_its_shapes(ra):
+    import torch
+    q = synth.normalish(7990, (4, 17, 8))
+    pq = ra.Pq(None, q)
+    pq.set_encode_variant(7)
+    with pytest.raises(Exception):
+        pq.quantize_batch_device(torch.from_numpy(synth.normalish(7991, (100, 32))).cuda())
