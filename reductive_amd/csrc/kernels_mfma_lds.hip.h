@@ -24,6 +24,10 @@
 #error "ENC_ABLATE produces wrong results: only `make TIMING=1` (libpqhip_timing.so, -DPQHIP_TIMING_ONLY_BUILD) may set it"
 #endif
 
+#ifndef ENC_HYBRID_OFF
+#define ENC_HYBRID_OFF 0    // 1: every distance takes its own LDS atomic also for short sub-vectors (the round-2 form; A/B builds)
+#endif
+
 namespace pqhip {
 
 // ---------------------------------------------------------------------------------------------
@@ -41,6 +45,9 @@ template <int T, int DP, bool VEC, typename IdxT>
 __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(EncodeArgs a)
 {
     constexpr int S = DP / 2;
+    // distances per step that are reduced lane-locally before the LDS atomic (see the epilogue), by chain length
+    constexpr int NL = (ENC_HYBRID_OFF || sizeof(IdxT) == 8) ? 0 : (S == 1 ? 6 : S == 2 ? 5 : S == 3 ? 3 : S == 4 ? 2 : 0);
+    constexpr int NA = NL > 0 ? 17 - NL : 16;      // atomics (the first one a plain store) per step
     __shared__ __attribute__((aligned(16))) float afrag_s[T][S][64];
     __shared__ __attribute__((aligned(16))) long long slot_s[4][T + 1][64];   // [T]: the tile fold's target
     __shared__ __attribute__((aligned(16))) float cc_s[T * 32];
@@ -270,6 +277,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
             __builtin_amdgcn_sched_barrier(0);
             // ---- VALU: 16 distances -> 16 keys ----
             long long key[16];
+            float dl[NL > 0 ? NL : 1];
 #pragma unroll
             for (int g = 0; g < 4 && ENC_ABLATE != 2; ++g) {
                 const f32x2 c01 = {c4[g][0], c4[g][1]}, c23 = {c4[g][2], c4[g][3]};
@@ -281,9 +289,25 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
                 for (int qq = 0; qq < 4; ++qq) {
                     const int r = 4 * g + qq;
                     const float d = ffma(acc[r], -2.0f, tt[qq]);
-                    key[r] = ((long long)__float_as_int(d) << 32) | (long long)(unsigned)lo[r];
+                    if (NL > 0 && r >= 16 - NL) dl[r - (16 - NL)] = d;
+                    else key[r] = ((long long)__float_as_int(d) << 32) | (long long)(unsigned)lo[r];
                 }
                 asm volatile("" ::"v"(t01), "v"(t23));
+            }
+            if constexpr (NL > 0) {
+                // short sub-vectors: the chain is 1-4 matrix instructions, so the 16 LDS atomics of a step -- not the
+                // matrix core -- set its length (one CU retires a 64-bit ds_min per ~6 cycles for all its waves).  The
+                // last NL distances are therefore reduced in the lane (strict < in ascending centroid order = first
+                // minimum; 3 vector instructions each) and enter the slot as ONE key: 17 - NL atomics per step.
+                float bd = dl[0];
+                int bi = lo[16 - NL];
+#pragma unroll
+                for (int e = 1; e < NL; ++e) {
+                    const bool lt = dl[e] < bd;
+                    bd = lt ? dl[e] : bd;
+                    bi = lt ? lo[16 - NL + e] : bi;
+                }
+                key[16 - NL] = ((long long)__float_as_int(bd) << 32) | (long long)(unsigned)bi;
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- next chain + this tile's atomics + next tile's norms (queued behind the atomics) ----
@@ -295,7 +319,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
                 nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(an[s], (t + 1 < T) ? bop[s] : bop_n[s],
                                                            nacc, 0, 0, 0);
 #pragma unroll
-                for (int r = (16 * s) / S; r < (16 * (s + 1)) / S; ++r) {
+                for (int r = (NA * s) / S; r < (NA * (s + 1)) / S; ++r) {
                     if (ENC_ABLATE == 2) continue;
                     if (ENC_ABLATE == 3) { asm volatile("" ::"v"(key[r])); continue; }
                     // the step's first key is stored (a ds_write instead of a read-modify-write, and the slot needs

@@ -579,9 +579,11 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         a.bad_flag = bad_flag;
         // kernel kind: 0 VALU argmin, 2 LDS argmin + LDS A fragments (variant 3, the retired
         // register-resident LDS-argmin kernel, is an alias of the default)
-        // auto: for sub-vectors of <= 4 floats the per-distance work outweighs the MFMA chain and the
-        // LDS pipe (one atomic per 64 distances) becomes the bound: the VALU-argmin kernel is 10-15 % faster
-        const bool tiny = cb->variant == 0 && cb->DP <= 4 && code_bytes == 1;
+        // auto: for sub-vectors of <= 2 floats the per-distance work outweighs the MFMA chain and the
+        // LDS pipe (one atomic per 64 distances) becomes the bound: the VALU-argmin kernel is 4-20 % faster
+        // (round 3: with the hybrid lane-local + LDS argmin of the default kernel, 4-float sub-vectors moved to the default:
+        // d=300 M=75 2.98e8 vs 2.80e8 vectors/s; 2-float ones stay here: M=150 1.62e8 vs 1.69e8, d=20 M=10 K=128 4.3e9 vs 5.1e9)
+        const bool tiny = cb->variant == 0 && cb->DP <= 2 && code_bytes == 1;
         // the VALU-argmin kernel keeps all T * DP/2 fragments in registers: small codebooks only
         const bool kind0_fits = cb->DP <= 32 && cb->T * (cb->DP / 2) <= 128 && code_bytes == 1;
         if (cb->variant == 2 && !kind0_fits) return PQHIP_EUNSUPPORTED;
