@@ -192,7 +192,7 @@ class Bench:
                 extra["layout"] = "interleaved %d-byte records (codes at 0, f32 scale at %d)" % (rec.shape[1], rec_off)
             kernel = "k_reconstruct<.., SEL>"
         elif workload == "adc_scan":
-            src = torch.randint(0, k, (rows, m), device=self.dev, dtype=torch.uint8, generator=g)
+            src = torch.randint(0, k, (rows, m), device=self.dev, dtype=torch.uint8 if k <= 256 else torch.int32, generator=g)
             nq = max(1, args.queries)
             query = torch.from_numpy(synth.normalish(45, (d,) if nq == 1 else (nq, d))).to(self.dev)
             dst = torch.empty((rows,) if nq == 1 else (nq, rows), device=self.dev, dtype=torch.float32)
@@ -249,7 +249,7 @@ class Bench:
             if workload == "lookup":
                 bytes_vec = 4 * d + m + 8 + 4     # output row + code row + row index + scale
             if workload == "adc_scan":
-                bytes_vec = m + 4 * max(1, args.queries)   # code row in, one f32 distance out per query
+                bytes_vec = m * (1 if k <= 256 else 4) + 4 * max(1, args.queries)   # code row in, one f32 distance out per query
             ach = bytes_vec * rows / sec / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                     "traffic": traffic, "kernel": kernel, "avg_launch_ms": kernel_ms, "min_launch_ms": kmin,
