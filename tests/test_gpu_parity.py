@@ -1059,6 +1059,27 @@ def test_resident_matrix_handle_feeds_the_training_entry_points(ra):
     L.pqhip_matrix_destroy(h)
 
 
+@pytest.mark.parametrize("d", [4, 20, 32, 40, 64, 72, 96, 100, 160, 256, 260, 288, 300, 320, 324, 352, 512, 600, 636, 640])
+def test_rotation_kernel_every_burst_structure(ra, d):
+    """k_rotate_pblock8 is compiled for the eight combinations of (rule-2 split d > 256, odd number of full 32-k bursts,
+    partial last burst); d = 4 .. 636 walks all of them plus the edges -- no full burst at all (d < 32), one burst, the
+    largest d whose P block fits LDS (636) and the first one that falls back (640) -- with enough rows (two row groups,
+    14 tiles for some waves, a ragged last tile) that the burst ring crosses tile and workgroup boundaries.  Bit-exact
+    against the oracle's rule-2 chains; non-contiguous rows and a wider output too."""
+    import torch
+    n = 4608 + 2 * 384 + 17
+    x = synth.normalish(2100 + d, (n, d))
+    P = synth.orthonormal(2101 + d, d) if d <= 320 else synth.normalish(2101 + d, (d, d)) * np.float32(0.05)
+    want = orc.rotate(x, P)
+    got = ra.rotate(torch.from_numpy(x).cuda(), P).cpu().numpy()
+    assert got.tobytes() == want.tobytes()
+    if d % 4 == 0 and d >= 20:
+        wide = torch.zeros((n, d + 8), device="cuda")
+        wide[:, :d] = torch.from_numpy(x).cuda()
+        got2 = ra.rotate(wide[:, :d], P).cpu().numpy()
+        assert got2.tobytes() == want.tobytes()
+
+
 def test_rotate_entry_point_and_gaussian_opq(ra, kats):
     """`instances.dot(&projection)` alone (rule 2, bit-exact) and `GaussianOpq::train_pq_using`
     (gaussian_opq.rs:99-108: mean Euclidean loss < 0.12 on U[0,1) 256 x 20)."""
