@@ -96,13 +96,13 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def load_pmc_traffic(workload, rows, d, m, k):
+def load_pmc_traffic(workload, rows, d, m, k, suffix=""):
     """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3 --pmc
     passes (profiles/pmc_traffic.json, written by tools/pmc_summarize.py).  Refused (None + reason)
     unless the record was taken for exactly this workload size AND on the kernel sources of this build."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        rec = json.load(open(p))["entries"].get("%s@%d@d%d_m%d_k%d" % (workload, rows, d, m, k))
+        rec = json.load(open(p))["entries"].get("%s@%d@d%d_m%d_k%d%s" % (workload, rows, d, m, k, suffix))
     except Exception:
         return None, "no profiles/pmc_traffic.json"
     if not rec:
@@ -243,7 +243,7 @@ class Bench:
             extra["encode_kernel" if workload not in ("reconstruct", "opq_reconstruct", "lookup", "adc_scan") else "kernel"] = kernel
 
         sec = kernel_ms * 1e-3
-        traffic_rec, why = load_pmc_traffic(workload, rows, d, m, k)
+        traffic_rec, why = load_pmc_traffic(workload, rows, d, m, k, "_q%d" % args.queries if (workload == "adc_scan" and args.queries > 1) else "")
         traffic = traffic_rec["hbm_bytes_per_launch"] if traffic_rec else None
         if workload in ("reconstruct", "lookup", "adc_scan"):
             if workload == "lookup":

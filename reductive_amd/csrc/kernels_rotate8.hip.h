@@ -39,6 +39,21 @@
 
 namespace pqhip {
 
+// GATHER form (pq.rs:323-326 without the intermediate matrix): the "x" of the rotation is the reconstruction of a code row,
+// x[row][k] = cb[m][codes[row][m]][k - m dsub] (primitives.rs:141-147), fetched piece by piece from the L2-resident codebook
+// while the previous burst multiplies -- the gathered rows never exist in memory.  Needs dsub % 4 == 0 (a 16-byte piece
+// lies inside one sub-vector).  sel_rows != nullptr: output row i reconstructs code row sel_rows[i] (lookup form).
+struct Rot8Gather {
+    const uint8_t* codes = nullptr;   // [n_codes or n][c_rs], 1-byte codes
+    int64_t c_rs = 0;
+    const float* cb = nullptr;     // [M][K][dsub]
+    int K = 0, dsub = 0;
+    unsigned inv_dsub = 0;         // ceil(2^32 / dsub): k / dsub == umulhi(k, inv_dsub) for k < 65536
+    const int64_t* sel_rows = nullptr;
+    int64_t n_codes = 0;
+    int* err = nullptr;            // "code >= K / row index out of range" flag (as k_reconstruct)
+};
+
 struct Rot8Ops {           // LDS operands of one 4-k group: two k-steps x two column tiles
     f32x2 p0, p1;
 };
@@ -89,13 +104,16 @@ __device__ __forceinline__ void rot8_swap(const f32x4 (&s)[4], float (&xo)[16])
 // ODD: odd number of full 32-k bursts; TAIL: d % 32 != 0 (a partial last burst).  Compile-time facts so that the burst
 // sequence of a tile is ONE straight code path: with a run-time choice between the full and the partial burst the
 // register allocator gave the two paths different accumulator registers and copied all 32 of them at every join.
-template <bool SPLITK, bool ODD, bool TAIL>
-__global__ __launch_bounds__(768, 3) void k_rotate_pblock8(const float* __restrict__ x, int64_t n, int64_t x_rs,
+// GATHER runs 8 waves per workgroup (two per SIMD, 256 registers each): the gather's address arithmetic does not fit beside
+// two accumulator pairs and two burst buffers in the 168 registers of the three-waves-per-SIMD form (58 spilled).
+template <bool SPLITK, bool ODD, bool TAIL, bool GATHER>
+__global__ __launch_bounds__(GATHER ? 512 : 768, GATHER ? 2 : 3) void k_rotate_pblock8(const float* __restrict__ x, int64_t n, int64_t x_rs,
                                                            const float* __restrict__ Pm, int d, float* __restrict__ out,
-                                                           int64_t o_rs, int rows_per_wg, int ncb, int64_t rg_per_xcd, int dyn_tiles,
+                                                           int64_t o_rs, int rows_per_wg, int ncb, int64_t rg_per_xcd, Rot8Gather ga,
                                                            unsigned long long* stamps /* diagnostics: PQHIP_DEBUG_ROT_STAMP */)
 {
-    constexpr int NWAVE = 12;
+    constexpr int NWAVE = GATHER ? 8 : 12;
+    constexpr int NT = 64 * NWAVE;               // threads per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem8[];
     float* pl = smem8;                           // [ceil(d/4) + 1 groups][64 cols][4]; the last group is never used as data
     const unsigned long long st_in = stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -111,25 +129,22 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock8(const float* __restri
     const int64_t rg_local = q / ncb;
     const int64_t rg = rg_local * 8 + xcd;
     const int col0 = cb * 64;
-    // next 32-row tile of this workgroup that no wave has taken yet (behind the P image and its spare group)
-    unsigned* const tile_ctr = reinterpret_cast<unsigned*>(smem8 + ((size_t)((d + 3) >> 2) + 1) * 256);
-    if (tid == 0) *tile_ctr = NWAVE;
 
     // stage the P block: 16-byte loads, two in flight per thread before the LDS stores; image order (k0, k2, k1, k3)
     {
         const int total = d * 16;                // float4 per block: d rows x 16
-        for (int i0 = tid; i0 < total; i0 += 768 * 2) {
+        for (int i0 = tid; i0 < total; i0 += NT * 2) {
             f32x4 v[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int idx = i0 + 768 * u;
+                const int idx = i0 + NT * u;
                 const int k = idx >> 4, c = col0 + 4 * (idx & 15);
                 v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (idx < total && c < d) v[u] = *reinterpret_cast<const f32x4*>(Pm + (int64_t)k * d + c);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int idx = i0 + 768 * u;
+                const int idx = i0 + NT * u;
                 if (idx < total) {
                     const int k = idx >> 4, c4 = idx & 15;
                     const int inner = ((k & 1) << 1) | ((k >> 1) & 1);
@@ -155,33 +170,57 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock8(const float* __restri
     const int nb = nfull + (TAIL ? 1 : 0);
     constexpr int KB = kKC / 32;                 // bursts per rule-2 block
 
-    // Tiles are handed out dynamically: the three waves of a SIMD do not share its matrix pipe evenly (the oldest wave
-    // wins the arbitration), and with a fixed 12 tiles per wave the favoured waves finished after 534 k cycles, the
-    // starved ones after 1.1 M -- running alone, below the pipe's rate, for the last third of the workgroup's life
-    // (stamps, round 3).  Each wave takes its next tile from an LDS counter one tile ahead (the next tile's first
-    // burst is requested during the current tile's last one).
+    // Tiles are assigned statically (wave w takes tiles w, w + 12, ..).  The three waves of a SIMD do not share its matrix pipe
+    // evenly -- the oldest wins the arbitration: 534 k to 1.1 M cycles of wave life for the same 12 tiles -- but that is harmless:
+    // the last wave of a SIMD runs alone at the full rate.  Handing tiles out from an LDS counter was measured and removed
+    // (7-17 tiles per wave, 70 k instead of 60 k cycles per tile, OPQ step 30.9 vs 30.5 ms).
     const int ntile = (int)((wg_row1 - wg_row0 + 31) >> 5);
     int64_t row0 = wg_row0 + 32 * wave;
     if (row0 >= wg_row1) return;
     int cur_tile = wave;
-    auto row_ptr = [&](int64_t r0) {             // this lane's row of the tile at r0 (clamped to the last row), its half's 16 k
+    bool bad = false;                            // GATHER: a code >= K or a row index out of range was met
+    // this lane's row of the tile at r0 (clamped to the last row): pointer to its half's 16 k, or -- GATHER -- the byte offset
+    // of its code row in the code matrix (32-bit offsets against uniform bases keep the gather's addressing in one VGPR each)
+    struct RowRef { const float* p; unsigned co; };
+    auto row_ref = [&](int64_t r0) -> RowRef {
         const int64_t r = (r0 + j < n) ? r0 + j : n - 1;
-        return x + r * x_rs + 16 * h;
+        if constexpr (GATHER) {
+            int64_t src = r;
+            if (ga.sel_rows) {
+                src = ga.sel_rows[r];
+                if (src < 0 || src >= ga.n_codes) { bad = true; src = 0; }
+            }
+            return RowRef{nullptr, (unsigned)(src * ga.c_rs)};
+        } else {
+            return RowRef{x + r * x_rs + 16 * h, 0u};
+        }
     };
     bool loads_on = true;
-    auto load_full = [&](f32x4 (&s)[4], const float* pb) {
-        if (!loads_on) { asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3])); return; }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] = *reinterpret_cast<const f32x4*>(pb + 4 * e);
+    // one 16-byte piece of a gathered row: floats k0 .. k0 + 3 of the reconstruction of the code row at byte offset co
+    auto gather_piece = [&](unsigned co, int k0) -> f32x4 {
+        const unsigned m = __umulhi((unsigned)k0, ga.inv_dsub);
+        const unsigned off = (unsigned)k0 - m * (unsigned)ga.dsub;
+        unsigned code = *(ga.codes + (co + m));                                   // (1-byte codes only: the host falls back otherwise)
+        bad |= code >= (unsigned)ga.K;
+        code = code < (unsigned)ga.K ? code : 0u;
+        const unsigned boff = ((m * (unsigned)ga.K + code) * (unsigned)ga.dsub + off) * 4u;   // < 2^26: the codebook is at most 64 MB
+        return *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(ga.cb) + boff);
     };
-    auto load_tail = [&](f32x4 (&s)[4], const float* pb) {   // burst nfull: pieces past the row's end are zero
+    auto load_burst = [&](f32x4 (&s)[4], const RowRef& rr, int bi, bool full) {   // burst bi of the tile whose row is rr
         if (!loads_on) { asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3])); return; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            s[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (32 * nfull + 16 * h + 4 * e < d) s[e] = *reinterpret_cast<const f32x4*>(pb + 4 * e);
+            const int k0 = 32 * bi + 16 * h + 4 * e;
+            if (full || k0 < d) {
+                if constexpr (GATHER) s[e] = gather_piece(rr.co, k0);
+                else s[e] = *reinterpret_cast<const f32x4*>(rr.p + 32 * bi + 4 * e);
+            } else {
+                s[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
+    auto load_full = [&](f32x4 (&s)[4], const RowRef& rr, int bi) { load_burst(s, rr, bi, true); };
+    auto load_tail = [&](f32x4 (&s)[4], const RowRef& rr) { load_burst(s, rr, nfull, false); };   // pieces past the row's end are zero
     // the tile in (t0, t1) leaves the accumulators as 16-byte row pieces: register 4 g + e of lane (row j, half h) is
     // column 32 ct + 8 g + 4 h + e
     auto store_tile = [&](const f32x16& t0, const f32x16& t1, int64_t r0) {
@@ -205,8 +244,8 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock8(const float* __restri
     };
 
     f32x4 sa[4], sb[4];
-    const float* prow = row_ptr(row0);
-    if (nfull > 0) load_full(sa, prow); else load_tail(sa, prow);
+    RowRef prow = row_ref(row0);
+    if (nfull > 0) load_full(sa, prow, 0); else load_tail(sa, prow);
     if (ROT8_ABLATE == 2 || ROT8_ABLATE == 4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) sb[e] = sa[e];
@@ -221,15 +260,10 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock8(const float* __restri
     const unsigned long long st_t0 = stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     for (;;) {
         const unsigned long long st_a = stamps ? __builtin_amdgcn_s_memtime() : 0;
-        int next_tile = cur_tile + NWAVE;
-        if (dyn_tiles) {
-            unsigned nt_ = 0;
-            if (lane == 0) nt_ = atomicAdd(tile_ctr, 1u);
-            next_tile = __builtin_amdgcn_readfirstlane((int)nt_);
-        }
+        const int next_tile = cur_tile + NWAVE;
         const bool has_next = next_tile < ntile;
         const int64_t next_row0 = wg_row0 + 32 * (int64_t)next_tile;
-        const float* pnext = has_next ? row_ptr(next_row0) : prow;
+        const RowRef pnext = has_next ? row_ref(next_row0) : prow;
         f32x16 c0 = zero, c1 = zero;
         // One burst.  Order matters: the operands of THIS burst are formed first (the compiler's vmcnt(0) in front of
         // the swaps then waits for nothing younger), THEN burst bi + 1 (or the next tile's burst 0) is requested into
@@ -239,9 +273,9 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock8(const float* __restri
         {                                                                                              \
             float xo_[16];                                                                             \
             rot8_swap(cu, xo_);                                                                        \
-            if ((bi) + 1 < nfull) load_full(nx, prow + 32 * ((bi) + 1));                               \
-            else if (TAIL && (bi) + 1 == nfull) load_tail(nx, prow + 32 * nfull);                      \
-            else if (has_next) { if (nfull > 0) load_full(nx, pnext); else load_tail(nx, pnext); }     \
+            if ((bi) + 1 < nfull) load_full(nx, prow, (bi) + 1);                                       \
+            else if (TAIL && (bi) + 1 == nfull) load_tail(nx, prow);                                   \
+            else if (has_next) { if (nfull > 0) load_full(nx, pnext, 0); else load_tail(nx, pnext); }  \
             if ((bi) == 0 && pending) store_tile(t0, t1, prev_row0);                                   \
             const float* pn_ = ((bi) + 1 < nb) ? plane + ((bi) + 1) * 8 * 256 : plane;                 \
             if (!(IS_TAIL)) rot8_burst<true>(plane + (bi) * 8 * 256, pn_, 8, xo_, c0, c1, ops);        \
@@ -293,6 +327,7 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock8(const float* __restri
         cur_tile = next_tile;
     }
     if (pending) store_tile(t0, t1, prev_row0);
+    if (GATHER && bad) atomicOr(ga.err, 1);
     if (stamps && lane == 0) {
         unsigned long long* o = stamps + ((size_t)blockIdx.x * NWAVE + wave) * 8;
         o[0] = st_tiles; o[1] = st_k; o[2] = st_t0 - st_in;   // [2]: P staging + barrier

@@ -660,21 +660,24 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
 
 
 // out[n][d] = x[n][d] . Pm   on the device
+// ga != nullptr: the rows are gathered from the codebook inside the rotation kernel (Rot8Gather); returns
+// PQHIP_EUNSUPPORTED when the shape has no such kernel (the caller then gathers into a scratch buffer first).
 int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, int d, float* d_out,
-                   int64_t o_rs, hipStream_t st)
+                   int64_t o_rs, hipStream_t st, const Rot8Gather* ga = nullptr)
 {
     if (n == 0) return PQHIP_OK;
-    const bool vec = (d % 4 == 0) && (x_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
+    const bool vec = ga ? (d % 4 == 0 && ga->dsub % 4 == 0)
+                        : (d % 4 == 0) && (x_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
     const int kpad = (d + 3) & ~3;
     const size_t pblock_bytes = (size_t)kpad * 64 * sizeof(float);
     {
         // v8: P block in LDS, x rows straight from global memory into the MFMA operands, direct 16-byte stores
         // from the accumulators (kernels_rotate8.hip.h); same launch geometry as v6
-        const size_t lds8 = ((size_t)((d + 3) / 4) + 1) * 256 * sizeof(float) + 16;   // P image + spare group + tile counter
+        const size_t lds8 = ((size_t)((d + 3) / 4) + 1) * 256 * sizeof(float);   // P image + one spare group (pre-reads past the last group)
         static const bool use_v8 = getenv("PQHIP_DEBUG_NO_GEMM8") == nullptr;
         const bool out_vec8 = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
         if (use_v8 && vec && out_vec8 && lds8 <= 160 * 1024) {
-            const int rows_per_wg = rot_rows_per_wg();   // 12 waves x 12 tiles of 32 rows
+            const int rows_per_wg = ga ? rot_rows_per_wg() / 12 * 8 : rot_rows_per_wg();   // 12 (gather form: 8) waves x 12 tiles of 32 rows
             const int ncb = (d + 63) / 64;
             const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
             const int64_t rg_per_xcd = (n_rg + 7) / 8;
@@ -686,20 +689,21 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
                 PQCHK(stamp_buf.alloc(n_stamp * sizeof(unsigned long long)));
                 HIPCHK(hipMemsetAsync(stamp_buf.p, 0, n_stamp * sizeof(unsigned long long), st));
             }
-            static const int dyn_tiles = getenv("PQHIP_DEBUG_ROT8_STATIC") == nullptr;
             // template facts: rule-2 split (d > 256), odd number of full 32-k bursts, partial last burst
             const bool splitk = d > kKC, odd = ((d >> 5) & 1) != 0, tail = (d & 31) != 0;
-#define LAUNCH_ROT8(S, O, T)                                                                                        \
+#define LAUNCH_ROT8G(S, O, T, G)                                                                                    \
             do {                                                                                                    \
-                HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock8<S, O, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                hipLaunchKernelGGL((k_rotate_pblock8<S, O, T>), grid, dim3(768), lds8, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, \
-                                   rg_per_xcd, dyn_tiles, (unsigned long long*)stamp_buf.p);                        \
+                HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock8<S, O, T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                hipLaunchKernelGGL((k_rotate_pblock8<S, O, T, G>), grid, dim3(G ? 512 : 768), lds8, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, \
+                                   rg_per_xcd, ga ? *ga : Rot8Gather{}, (unsigned long long*)stamp_buf.p);           \
             } while (0)
+#define LAUNCH_ROT8(S, O, T) do { if (ga) LAUNCH_ROT8G(S, O, T, true); else LAUNCH_ROT8G(S, O, T, false); } while (0)
             if (splitk) { if (odd) { if (tail) LAUNCH_ROT8(true, true, true); else LAUNCH_ROT8(true, true, false); }
                           else     { if (tail) LAUNCH_ROT8(true, false, true); else LAUNCH_ROT8(true, false, false); } }
             else        { if (odd) { if (tail) LAUNCH_ROT8(false, true, true); else LAUNCH_ROT8(false, true, false); }
                           else     { if (tail) LAUNCH_ROT8(false, false, true); else LAUNCH_ROT8(false, false, false); } }
 #undef LAUNCH_ROT8
+#undef LAUNCH_ROT8G
             HIPCHK(hipGetLastError());
             if (want_stamps) {   // diagnostics: synchronous summary on stderr
                 std::vector<unsigned long long> h(n_stamp);
@@ -726,6 +730,7 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
             return PQHIP_OK;
         }
     }
+    if (ga) return PQHIP_EUNSUPPORTED;           // only v8 gathers inside the kernel
     {
         // v6: as v5 with three waves per SIMD (12-wave workgroups, 16-k slabs)
         const size_t lds6 = ((size_t)((d + 3) / 4) * 256 + (size_t)12 * 2 * 32 * 20) * sizeof(float);
@@ -1424,8 +1429,30 @@ int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, 
     int* err = err_flag_for(cb, slot, st);
     if (!cb->has_proj)
         return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st, err, sel_rows, n_codes, sel_scales, s_rs);
-    // OPQ (pq.rs:323-326): gather into a leased scratch buffer, then out = r.dot(P^T); a lookup's scale comes last
     CodebookDev& cd = cb->dev[slot];
+    // OPQ (pq.rs:323-326) in ONE kernel when the rotation kernel can gather (sub-vectors of whole 16-byte pieces, P block
+    // within LDS): the reconstructed rows never exist in memory, no scratch buffer.  PQHIP_DEBUG_NO_GATHER_ROT=1: the
+    // round-2 form below (gather -> scratch -> rotate), for A/B.
+    static const bool fused_off = getenv("PQHIP_DEBUG_NO_GATHER_ROT") != nullptr;
+    const int64_t code_rows = sel_rows ? n_codes : n;
+    if (!fused_off && code_bytes == 1 && cb->dsub % 4 == 0 && cb->d < 65536 && cb->M * cb->K * cb->dsub < (1 << 24) &&
+        code_rows * c_rs < (1ll << 32)) {
+        Rot8Gather ga;
+        ga.codes = (const uint8_t*)d_codes; ga.c_rs = c_rs; ga.cb = cd.cb; ga.K = (int)cb->K; ga.dsub = (int)cb->dsub;
+        ga.inv_dsub = (unsigned)(((1ull << 32) + cb->dsub - 1) / cb->dsub);
+        ga.sel_rows = sel_rows; ga.n_codes = n_codes; ga.err = err;
+        const int32_t rc = rotate_dev(nullptr, n, 0, cd.PT, (int)cb->d, d_out, o_rs, st, &ga);
+        if (rc == PQHIP_OK) {
+            if (sel_rows && sel_scales) {
+                const unsigned g = (unsigned)std::min<int64_t>((n * cb->d + 255) / 256, 256 * 32);
+                hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, st, d_out, n, (int)cb->d, o_rs, sel_rows, n_codes, sel_scales, s_rs);
+                HIPCHK(hipGetLastError());
+            }
+            return PQHIP_OK;
+        }
+        if (rc != PQHIP_EUNSUPPORTED) return rc;
+    }
+    // otherwise: gather into a leased scratch buffer, then out = r.dot(P^T); a lookup's scale comes last
     const int64_t chunk = opq_chunk_rows(cb, slot, n);
     ScratchLease rec(cb, slot, st);
     PQCHK(rec.acquire((size_t)chunk * cb->d * sizeof(float)));

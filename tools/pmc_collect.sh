@@ -11,10 +11,12 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-WL=${*:-"encode opq_encode reconstruct reconstruct100 encode_d768 lookup adc_scan"}
+WL=${*:-"encode opq_encode reconstruct reconstruct100 encode_d768 lookup adc_scan adc_scan8 opq_reconstruct kmeans opq_train smallk"}
 for W in $WL; do
   case $W in
     reconstruct100) ARGS="--workload reconstruct --rows 100000000";;
+    adc_scan8) ARGS="--workload adc_scan --queries 8";;
+    smallk) ARGS="--workload encode --d 128 --m 16 --k 16";;
     *) ARGS="--workload $W";;
   esac
   CMD="$R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-sub-configs"

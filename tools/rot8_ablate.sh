@@ -9,6 +9,5 @@ if [ "$1" = build ]; then
   wait; ls tools/rot8_ablate_?
 else
   for r in 1 2; do for a in 0 1 2 3 4; do timeout -k 5 60 tools/rot8_ablate_$a ${1:-2.0} 0; done; done
-  timeout -k 5 60 tools/rot8_ablate_0 ${1:-2.0} 1
   echo "plain stores:"; timeout -k 5 60 tools/rot8_ablate_s ${1:-2.0} 0; timeout -k 5 60 tools/rot8_ablate_0 ${1:-2.0} 0; timeout -k 5 60 tools/rot8_ablate_s ${1:-2.0} 0
 fi
