@@ -31,6 +31,7 @@
 #include "kernels_pair16.hip.h"
 #include "encode_launch.h"
 #include "opq_fused_launch.h"
+#include "opq_fused2_launch.h"
 #include "smallk_launch.h"
 
 using namespace pqhip;
@@ -505,7 +506,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
                          const int* bad_flag = nullptr)
 {
     if (n == 0) return PQHIP_OK;
-    if (cb->variant == 5 && !cb->has_proj) return PQHIP_EUNSUPPORTED;   // variant 5 = fused OPQ kernel only
+    if ((cb->variant == 5 || cb->variant == 8) && !cb->has_proj) return PQHIP_EUNSUPPORTED;   // variants 5 / 8 = fused OPQ kernels only
     CodebookDev& cd = cb->dev[slot];
     if (cb->groups > 1 && cb->variant != 1 && cb->norms_ok && code_bytes == 4)
         return encode_grouped_dev(cb, slot, d_x, n, x_rs, d_codes, o_rs, st);
@@ -1360,6 +1361,61 @@ int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_
     // codes from a 97..256-centroid codebook with finite norms, an even sub-dimension <= 32 that has an
     // instantiation, 16-byte aligned rows and a P block that fits LDS (d <= 316).  Measured 5 % slower than
     // the two-kernel path below on the 10 M x 300 shape (numbers in the kernel's header), hence not the default.
+    // Second-generation fused kernel (kernels_opq_fused2.hip.h: P block AND codebook fragments in LDS, x straight from global
+    // memory): encode variant 8 forces it, PQHIP_FUSED2_OPQ=1 makes the auto variant take it where it is instantiated.
+    {
+        const int DP = (int)cb->dsub;
+        // Default for the shapes it is instantiated for (same-box A/B, 10 M x 300: 29.95 vs 30.57 ms in steady state, and the
+        // HBM traffic of a step drops from 3.5x to ~1x the algorithmic bytes); PQHIP_FUSED2_OPQ=0 keeps the two-kernel path.
+        static const bool fused2_off = [] { const char* e = getenv("PQHIP_FUSED2_OPQ"); return e && e[0] == '0'; }();
+        const bool want2 = cb->variant == 8 || (cb->variant == 0 && !fused2_off);
+        const bool vec = (cb->d % 4 == 0) && (x_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) & 15) == 0);
+        if (want2 && code_bytes == 1 && cb->groups == 1 && cb->T != 0 && cb->norms_ok && cb->dsub % 2 == 0 && cb->dsub <= 32 && vec &&
+            opq_fused2_has(DP, cb->T, (int)cb->d)) {
+            OpqFusedArgs a;
+            a.x = d_x; a.n = n; a.x_rs = x_rs; a.P = cd.P; a.d = (int)cb->d;
+            a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
+            a.out = (uint8_t*)d_codes; a.o_rs = o_rs;
+            a.M = (int)cb->M; a.K = (int)cb->K; a.k_pad = cb->k_pad;
+            const int nm = 64 / DP;
+            a.ncb = (int)((cb->M + nm - 1) / nm);
+            // tiles of 32 rows per wave: as many as leave ~8 rounds of workgroups (one per CU) for the whole launch, 4 .. 96
+            // (10 M x 300, one box: 12 tiles 29.84 ms, 24: 29.57, 48: 29.40, 96: 29.24, 160: 30.6, 192 (4 rounds): 38.8 --
+            // the P block and three fragment sets, 138 KB, are staged once per workgroup)
+            static const int f2_tiles_env = [] { const char* e = getenv("PQHIP_DEBUG_FUSED2_TILES"); return e ? std::max(1, atoi(e)) : 0; }();
+            const int64_t want_rg = std::max<int64_t>(1, 8ll * cb->ctx->devs[slot]->n_cus / a.ncb);
+            const int f2_tiles = f2_tiles_env ? f2_tiles_env : (int)std::max<int64_t>(4, std::min<int64_t>(96, (n / want_rg + 255) / 256));
+            a.rows_per_wg = 8 * 32 * f2_tiles;              // 8 waves x f2_tiles tiles of 32 rows
+            const int64_t n_rg = (n + a.rows_per_wg - 1) / a.rows_per_wg;
+            a.rg_per_xcd = (n_rg + 7) / 8;
+            const dim3 grid((unsigned)(a.rg_per_xcd * a.ncb * 8));
+            a.stamps = nullptr;
+            static const bool want_stamps = getenv("PQHIP_DEBUG_FUSED_STAMP") != nullptr;
+            DevBuf stamp_buf;
+            const size_t n_stamp = (size_t)grid.x * 8 * 5;
+            if (want_stamps) {
+                PQCHK(stamp_buf.alloc(n_stamp * sizeof(unsigned long long)));
+                HIPCHK(hipMemsetAsync(stamp_buf.p, 0, n_stamp * sizeof(unsigned long long), st));
+                a.stamps = (unsigned long long*)stamp_buf.p;
+            }
+            const int e = launch_opq_fused2(DP, cb->T, a, grid, st);
+            if (e != 0) { g_hip_err = std::string("k_opq_encode_fused2: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "no instantiation"); return PQHIP_EHIP; }
+            if (want_stamps) {   // diagnostics: synchronous summary on stderr
+                std::vector<unsigned long long> h(n_stamp);
+                HIPCHK(hipMemcpyAsync(h.data(), stamp_buf.p, n_stamp * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                double tiles = 0, rot = 0, enc = 0, cyc = 0, rt = 0; size_t waves = 0;
+                for (size_t i = 0; i < n_stamp; i += 5)
+                    if (h[i]) { tiles += (double)h[i]; rot += (double)h[i + 1]; enc += (double)h[i + 2]; cyc += (double)h[i + 3]; rt += (double)h[i + 4]; ++waves; }
+                if (tiles > 0)
+                    fprintf(stderr, "[pqhip] fused2 stamps: %zu waves, %.1f tiles/wave, rotation %.0f cyc/tile, encode %.0f cyc/tile, wave life %.0f cyc, clock %.0f MHz\n",
+                            waves, tiles / waves, rot / tiles, enc / tiles, cyc / waves, rt > 0 ? cyc / rt * 100.0 : 0.0);
+            }
+            cb->last_kernel = "k_opq_encode_fused2";
+            return PQHIP_OK;
+        }
+        if (cb->variant == 8) return PQHIP_EUNSUPPORTED;
+    }
     {
         const int DP = (int)cb->dsub;
         static const bool env_fused = getenv("PQHIP_FUSED_OPQ") != nullptr;
@@ -1720,7 +1776,7 @@ int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && c
 
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {
-    if (!cb || variant < 0 || variant > 7) return PQHIP_EINVAL;
+    if (!cb || variant < 0 || variant > 8) return PQHIP_EINVAL;
     cb->variant = variant;
     return PQHIP_OK;
 }

@@ -110,3 +110,80 @@ def test_fused_one_million_rows_every_code(ra):
     got = pq.quantize_batch_device(x).cpu().numpy()
     want = orc.quantize_batch(q, x.cpu().numpy(), projection=P, n_threads=16)
     assert got.tobytes() == want.tobytes()
+
+
+# ---- second generation (encode variant 8, kernels_opq_fused2.hip.h): P block AND codebook fragments in LDS, x straight from
+# global memory.  Instantiated for (dsub 20, d = 300-like: split, odd, tail) and (dsub 16: d = 256 and d = 320). --------------
+def _fused2(ra, q, P):
+    pq = ra.Pq(P, q)
+    pq.set_encode_variant(8)
+    return pq
+
+
+@pytest.mark.parametrize("n,M,K,dsub", [(200_003, 15, 256, 20), (50_001, 16, 256, 16), (40_000, 20, 256, 16), (31, 15, 256, 20),
+                                        (1, 15, 256, 20), (3073, 15, 256, 20), (9000, 15, 250, 20), (6145, 16, 225, 16)])
+def test_fused2_codes_equal_oracle(ra, n, M, K, dsub):
+    import torch
+    d = M * dsub
+    q = synth.normalish(6500 + d + K, (M, K, dsub))
+    P = synth.orthonormal(6501 + d, d)
+    x = synth.normalish(6502 + n, (n, d))
+    pq = _fused2(ra, q, P)
+    want = orc.quantize_batch(q, x, projection=P, n_threads=8)
+    got = pq.quantize_batch_device(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    assert pq.last_encode_kernel() == "k_opq_encode_fused2"
+    assert got.cpu().numpy().tobytes() == want.tobytes()
+    assert pq.quantize_batch(x).tobytes() == want.tobytes()          # host-buffer entry point, same kernel
+    wide = torch.zeros((n, d + 12), device="cuda")
+    wide[:, :d] = torch.from_numpy(x).cuda()
+    assert pq.quantize_batch_device(wide[:, :d]).cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_fused2_special_values_take_the_exact_path(ra):
+    import torch
+    M, K, dsub = 15, 256, 20
+    d = M * dsub
+    q = synth.normalish(6600, (M, K, dsub))
+    P = synth.orthonormal(6601, d)
+    x = synth.normalish(6602, (4096, d))
+    pick = synth.codes_u8(6603, (512, M), K).astype(np.int64)
+    cent = np.concatenate([q[m, pick[:, m]] for m in range(M)], axis=1)
+    x[100:612] = (cent.astype(np.float64) @ P.T.astype(np.float64)).astype(np.float32)
+    x[700, 3] = np.nan
+    x[701, 250] = np.inf
+    x[702] = -np.inf
+    x[703] *= np.float32(1e19)
+    x[704] = 0.0
+    x[705] = np.float32(1e-30)
+    x[4095, 0] = np.nan
+    pq = _fused2(ra, q, P)
+    with np.errstate(all="ignore"):
+        want = orc.quantize_batch(q, x, projection=P, n_threads=8)
+    got = pq.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert pq.last_encode_kernel() == "k_opq_encode_fused2"
+    assert got.tobytes() == want.tobytes()
+
+
+def test_fused2_refuses_shapes_without_an_instantiation(ra):
+    import torch
+    for M, K, dsub in ((24, 200, 10), (2, 128, 32), (26, 256, 12), (12, 256, 20)):   # other dsub; T = 4; d = 312; d = 240 (no split)
+        d = M * dsub
+        pq = _fused2(ra, synth.normalish(6700 + d, (M, K, dsub)), synth.orthonormal(6701 + d, d))
+        x = torch.from_numpy(synth.normalish(6702, (100, d))).cuda()
+        with pytest.raises(ra.PqHipError, match="unsupported"):
+            pq.quantize_batch_device(x)
+
+
+def test_fused2_one_million_rows_every_code(ra):
+    import torch
+    M, K, dsub = 15, 256, 20
+    d = M * dsub
+    q = synth.normalish(6800, (M, K, dsub))
+    P = synth.orthonormal(6801, d)
+    g = torch.Generator(device="cuda").manual_seed(6802)
+    x = torch.empty((1_000_000, d), device="cuda").normal_(generator=g)
+    pq = _fused2(ra, q, P)
+    got = pq.quantize_batch_device(x).cpu().numpy()
+    want = orc.quantize_batch(q, x.cpu().numpy(), projection=P, n_threads=16)
+    assert got.tobytes() == want.tobytes()
