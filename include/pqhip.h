@@ -264,13 +264,14 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float 
 /* force a kernel variant for encode: 0 = auto, 1 = scalar VALU anchor kernel,
  * 2 = MFMA kernel with VALU argmin, 3 = MFMA + LDS-atomic argmin with register-resident codebook
  * fragments (2 waves/SIMD), 4 = MFMA + LDS-atomic argmin with LDS-resident fragments (3 waves/SIMD;
- * the auto choice), 5 = OPQ codebooks only: rotation and encode fused in one kernel, no scratch buffer
+ * the auto choice wherever variant 9 has no instantiation), 5 = OPQ codebooks only: rotation and encode fused in one kernel, no scratch buffer
  * (PQHIP_EUNSUPPORTED for shapes it has no instantiation for), 6 = the VALU kernel for small codebooks
  * (K <= 64, u8 codes; the auto choice for K <= 16 with sub-vectors of 6 or 8 floats, and of 4 floats below 48
  * subquantizers), 7 = K <= 16, sub-vectors of 2 / 4 / 8 / 16 floats: the kernel that serves two subquantizers per
  * matrix tile (the auto choice for 2 floats, and for 4 floats from 48 subquantizers on), 8 = OPQ codebooks only: the
  * second-generation fused kernel (P block and codebook fragments in LDS; the auto choice for the shapes it is instantiated
- * for, PQHIP_EUNSUPPORTED otherwise) */
+ * for, PQHIP_EUNSUPPORTED otherwise), 9 = the LDS-atomic argmin on the 16x16x4 matrix instruction, four waves per
+ * SIMD (the auto choice for >= 64 centroids and sub-vectors of 4, 8, .., 32 floats; PQHIP_EUNSUPPORTED otherwise) */
 int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);
 /* name of the encode kernel the last device call on this codebook launched ("" if none)        */
 const char *pqhip_last_encode_kernel(const pqhip_codebook *cb);

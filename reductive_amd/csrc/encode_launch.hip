@@ -1,10 +1,13 @@
 // encode_launch.hip -- compiled once per (PQ_KIND, PQ_T, PQ_DPSET) by the Makefile.
-// PQ_KIND 0: VALU-argmin kernel, 2: LDS-argmin kernel with LDS-resident fragments (the default).
+// PQ_KIND 0: VALU-argmin kernel, 2: LDS-argmin kernel with LDS-resident fragments, 3: the same epilogue on
+// v_mfma_f32_16x16x4_f32 with four waves per SIMD (kernels_mfma16.hip.h; the default where it is instantiated:
+// T >= 2, DP = dsub = 0 (mod 4), DPSET 0 only).
 // PQ_DPSET 0: padded sub-dimension DP = 0 (mod 4), 1: DP = 2 (mod 4), 2: wide sub-vectors DP in
 // {40, 48, 56, 64} (default kernel only).
 #include "encode_launch.h"
 #include <cstdlib>
 #include "kernels_mfma_lds.hip.h"
+#include "kernels_mfma16.hip.h"
 
 #if !defined(PQ_KIND) || !defined(PQ_T) || !defined(PQ_DPSET)
 #error "PQ_KIND, PQ_T and PQ_DPSET must be defined"
@@ -23,6 +26,17 @@ template <int KIND, int T, int DP>
 static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st)
 {
     const unsigned pad = debug_lds_pad();
+    if constexpr (KIND == 3) {
+        if constexpr (T >= 2 && DP % 4 == 0 && DP <= 32) {
+            if (!vec || a.rows_per_item > 32 * kMfma16MaxTiles) return false;
+            if (code_bytes == 1) hipLaunchKernelGGL((k_encode_mfma16<T, DP, uint8_t>), grid, dim3(256), pad, st, a);
+            else if (code_bytes == 4) hipLaunchKernelGGL((k_encode_mfma16<T, DP, uint32_t>), grid, dim3(256), pad, st, a);
+            else return false;
+            return true;
+        } else {
+            return false;
+        }
+    } else {
     if (code_bytes == 8) {   // key mode of grouped codebooks: default kernel, 8 tiles per group
         if constexpr (KIND == 2 && T == 8) {
             if (vec) hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, true, unsigned long long>), grid, dim3(256), pad, st, a);
@@ -50,6 +64,7 @@ static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid,
         else hipLaunchKernelGGL((k_encode_mfma_lds3<T, DP, false, uint8_t>), grid, dim3(256), pad, st, a);
     }
     return true;
+    }
 }
 
 template <int KIND, int T, int DPSET>

@@ -20,6 +20,7 @@ namespace pqhip {
 // equals fl(t - fl(dp + dp)) only while dp + dp cannot overflow; |dp| <= sqrt(xx * cc) keeps
 // that true with a wide margin below 2^100.
 constexpr float kBigNorm = 1.2676506e30f;  // 2^100
+constexpr int kMfma16MaxTiles = 64;        // k_encode_mfma16: row tiles per wave (rows_per_item <= 2048), one bit each in a 64-bit mask
 
 struct EncodeArgs {
     const float* x;      // [n][x_rs] rows, unit column stride

@@ -19,7 +19,9 @@
 #include "kernels_mfma.hip.h"
 
 #ifndef ENC_ABLATE
-#define ENC_ABLATE 0      // timing experiments only (results are wrong): 1 no fold/store, 2 no keys/atomics/fold, 3 no atomics, 4 no x loads
+#define ENC_ABLATE 0      // timing experiments only (results are wrong): 1 no fold/store, 2 no keys/atomics/fold, 3 no atomics, 4 no x loads,
+                          // 5 32-bit atomics (distance bits only), 6 fragments of tile 0 kept in registers (no LDS fragment reads),
+                          // 7 the chain as 2 S v_mfma_f32_16x16x4_f32 over four 4-register accumulators (same registers, same flop)
 #elif ENC_ABLATE != 0 && !defined(PQHIP_TIMING_ONLY_BUILD)
 #error "ENC_ABLATE produces wrong results: only `make TIMING=1` (libpqhip_timing.so, -DPQHIP_TIMING_ONLY_BUILD) may set it"
 #endif
@@ -201,6 +203,11 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
     if (row_begin + 32 <= last_tile0) prow += tile_step;
     load_tile(vn, (row_begin + 32 <= last_tile0) ? row_begin + 32 : last_tile0);
 
+    float a0[ENC_ABLATE == 6 ? S : 1];
+    if (ENC_ABLATE == 6) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) { a0[s] = afrag_s[0][s][lane]; asm volatile("" : "+v"(a0[s])); }
+    }
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
         const int64_t row = trow0 + j;
         const bool valid = row < a.n;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && (big != 0 || neg));
-        const unsigned need = (unsigned)(bal | (bal >> 32));  // rows of this tile that need the exact path
+        const unsigned need = (ENC_ABLATE >= 5) ? 0u : (unsigned)(bal | (bal >> 32));  // rows of this tile that need the exact path
         if (h == 0 && valid && !((need >> j) & 1u)) {
             if (KEYS) {
                 const float bd = (od < best) ? od : best;   // finite and >= 0 here
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
             }
             float an[S];  // A fragments of the NEXT chain: in flight while the VALU works below
 #pragma unroll
-            for (int s = 0; s < S; ++s) an[s] = afrag_s[(t + 1) % T][s][lane];
+            for (int s = 0; s < S; ++s) an[s] = (ENC_ABLATE == 6) ? a0[s] : afrag_s[(t + 1) % T][s][lane];
             __builtin_amdgcn_sched_barrier(0);
             // ---- VALU: 16 distances -> 16 keys ----
             long long key[16];
@@ -316,12 +323,28 @@ __global__ __launch_bounds__(256, (DP <= 32 ? 3 : 1)) void k_encode_mfma_lds3(En
             long long* slot = &slot_s[wave][t][lane];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
+                if (ENC_ABLATE == 7) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int q4 = (2 * s + u) & 3;
+                        f32x4 part = {nacc[4 * q4], nacc[4 * q4 + 1], nacc[4 * q4 + 2], nacc[4 * q4 + 3]};
+                        const float bo = (t + 1 < T) ? bop[s] : bop_n[s];
+                        part = __builtin_amdgcn_mfma_f32_16x16x4f32(u ? bo : an[s], u ? an[s] : bo, part, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) nacc[4 * q4 + e] = part[e];
+                    }
+                } else
                 nacc = __builtin_amdgcn_mfma_f32_32x32x2f32(an[s], (t + 1 < T) ? bop[s] : bop_n[s],
                                                            nacc, 0, 0, 0);
 #pragma unroll
                 for (int r = (NA * s) / S; r < (NA * (s + 1)) / S; ++r) {
                     if (ENC_ABLATE == 2) continue;
                     if (ENC_ABLATE == 3) { asm volatile("" ::"v"(key[r])); continue; }
+                    if (ENC_ABLATE == 5) {
+                        asm volatile("" ::"v"(key[r]));
+                        (void)__hip_atomic_fetch_min(reinterpret_cast<int*>(slot) + 1, (int)(key[r] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        continue;
+                    }
                     // the step's first key is stored (a ds_write instead of a read-modify-write, and the slot needs
                     // no re-arming after the previous row tile), the other 15 are min-ed into it
                     if (r == 0) __hip_atomic_store(slot, key[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

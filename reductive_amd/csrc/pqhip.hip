@@ -566,7 +566,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     // MFMA kernels: u8 codes from every variant, u32 codes (k-means assignments, wide index types)
     // from the default variant; K <= 256 here (larger K: encode_grouped_dev above, or the anchor)
     const bool mfma_possible = cb->groups == 1 && cb->T != 0 && (cb->norms_ok || bad_flag != nullptr) &&
-                               (code_bytes == 1 || (code_bytes == 4 && (cb->variant == 0 || cb->variant == 4)));
+                               (code_bytes == 1 || (code_bytes == 4 && (cb->variant == 0 || cb->variant == 4 || cb->variant == 9)));
     bool use_mfma = mfma_possible;
     if (cb->variant == 1) use_mfma = false;
     if (cb->variant >= 2 && !mfma_possible) return PQHIP_EUNSUPPORTED;
@@ -588,14 +588,20 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         // the VALU-argmin kernel keeps all T * DP/2 fragments in registers: small codebooks only
         const bool kind0_fits = cb->DP <= 32 && cb->T * (cb->DP / 2) <= 128 && code_bytes == 1;
         if (cb->variant == 2 && !kind0_fits) return PQHIP_EUNSUPPORTED;
-        const int kind = (cb->variant == 2 || tiny) ? 0 : 2;
+        // kind 3 (k_encode_mfma16: the same epilogue on v_mfma_f32_16x16x4_f32, four waves per SIMD) wherever it is
+        // instantiated: >= 64 centroids, every float of a sub-vector real and their number a multiple of 4
+        static const bool no_mfma16 = getenv("PQHIP_DEBUG_NO_MFMA16") != nullptr;
+        const bool kind3_fits = cb->T >= 2 && cb->DP <= 32 && cb->DP % 4 == 0 && cb->DP == cb->dsub && (code_bytes == 1 || code_bytes == 4);
+        if (cb->variant == 9 && !kind3_fits) return PQHIP_EUNSUPPORTED;
+        const int kind = (cb->variant == 2 || tiny) ? 0 : ((cb->variant == 9 || (cb->variant == 0 && !no_mfma16)) && kind3_fits) ? 3 : 2;
         dim3 grid;
-        if (kind == 2) {
+        if (kind >= 2) {
             // one workgroup = one subquantizer x 4 row streams (one per wave)
             static const int64_t rpi_max = [] { const char* e = getenv("PQHIP_DEBUG_RPI_MAX"); return e ? (int64_t)atoll(e) : (int64_t)1024; }();
             static const int64_t rpi_min = [] { const char* e = getenv("PQHIP_DEBUG_RPI_MIN"); return e ? (int64_t)atoll(e) : (int64_t)32; }();
             int64_t rpi = round_up((n * cb->M + 4 * 4096 - 1) / (4 * 4096), 32);
             rpi = std::max<int64_t>(rpi_min, std::min<int64_t>(rpi_max, rpi));
+            if (kind == 3) rpi = std::min<int64_t>(rpi, 32 * kMfma16MaxTiles);   // one bit per row tile in the wave's exact-path mask
             a.rows_per_item = (int)rpi;
             a.n_chunks = (n + 4 * rpi - 1) / (4 * rpi);       // row groups
             a.chunks_per_xcd = (a.n_chunks + 7) / 8;
@@ -618,7 +624,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         static const bool want_stamps = getenv("PQHIP_DEBUG_ENC_STAMP") != nullptr;
         DevBuf stamp_buf;
         const size_t n_stamp = (size_t)grid.x * 4 * 5;
-        if (want_stamps && kind == 2) {
+        if (want_stamps && kind >= 2) {
             PQCHK(stamp_buf.alloc(n_stamp * sizeof(unsigned long long)));
             HIPCHK(hipMemsetAsync(stamp_buf.p, 0, n_stamp * sizeof(unsigned long long), st));
             a.stamps = (unsigned long long*)stamp_buf.p;
@@ -638,7 +644,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         static const char* const names[3][3] = {{"k_encode_mfma<odd>", "k_encode_mfma<vec2>", "k_encode_mfma<vec4>"},
                                                 {"", "", ""},
                                                 {"k_encode_mfma_lds3<odd>", "k_encode_mfma_lds3<vec2>", "k_encode_mfma_lds3<vec4>"}};
-        cb->last_kernel = (!vec && cb->DP > 32) ? "k_encode_mfma_lds3<padded>" : names[kind][vec ? grp / 2 : 0];
+        cb->last_kernel = kind == 3 ? "k_encode_mfma16" : (!vec && cb->DP > 32) ? "k_encode_mfma_lds3<padded>" : names[kind][vec ? grp / 2 : 0];
     } else {
         const int64_t total = n * cb->M;
         const int block = 256;
@@ -1776,7 +1782,7 @@ int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && c
 
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {
-    if (!cb || variant < 0 || variant > 8) return PQHIP_EINVAL;
+    if (!cb || variant < 0 || variant > 9) return PQHIP_EINVAL;
     cb->variant = variant;
     return PQHIP_OK;
 }

@@ -459,7 +459,7 @@ class Pq:
 
     def set_encode_variant(self, variant):
         """test/bench knob (include/pqhip.h: pqhip_set_encode_variant): 0 auto, 1 scalar anchor kernel, 2 / 4 MFMA kernels,
-        5 fused OPQ kernel, 6 small-codebook VALU kernel, 7 pair kernel (K <= 16)."""
+        5 fused OPQ kernel, 6 small-codebook VALU kernel, 7 pair kernel (K <= 16), 8 second fused OPQ kernel, 9 16x16x4 MFMA kernel."""
         rc = _lib.lib().pqhip_set_encode_variant(self._cb(), variant)
         if rc != _lib.OK:
             raise _lib.PqHipError(rc)

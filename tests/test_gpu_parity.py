@@ -111,10 +111,17 @@ SHAPES = [  # n, M, K, dsub
 ]
 
 
+def _has_mfma16(K, dsub):
+    """shapes the 16x16x4 kernel (variant 9, the auto choice there) is instantiated for"""
+    return 32 < K <= 256 and dsub % 4 == 0 and dsub <= 32
+
+
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 9])
 def test_encode_matches_oracle(ra, shape, variant):
     n, M, K, dsub = shape
+    if variant == 9 and not _has_mfma16(K, dsub):
+        pytest.skip("no 16x16x4 instantiation for this shape")
     q = synth.normalish(100 + n, (M, K, dsub))
     x = synth.normalish(200 + n, (n, M * dsub))
     dt = np.uint8 if K <= 256 else np.uint16
@@ -127,6 +134,11 @@ def test_encode_matches_oracle(ra, shape, variant):
     if variant == 0 and K <= 256 and dsub <= 32:
         # auto: the VALU kernel for small codebooks with an instantiated sub-dimension, else an MFMA kernel
         assert pq.last_encode_kernel().startswith(("k_encode_mfma", "k_encode_smallk"))
+        assert (pq.last_encode_kernel() == "k_encode_mfma16") == _has_mfma16(K, dsub)
+    if variant == 9:
+        assert pq.last_encode_kernel() == "k_encode_mfma16"
+    if variant == 4:
+        assert pq.last_encode_kernel().startswith("k_encode_mfma_lds3")
 
 
 def test_encode_special_values(ra):
@@ -296,7 +308,7 @@ def test_wide_subvectors_on_the_matrix_path(ra, dsub):
         want = orc.quantize_batch(q, x, dtype=dt)
         pq = _pq(ra, q)
         assert pq.quantize_batch(x, dtype=dt).tobytes() == want.tobytes(), (n, M, K)
-        assert pq.last_encode_kernel().startswith("k_encode_mfma_lds3")
+        assert pq.last_encode_kernel().startswith(("k_encode_mfma_lds3", "k_encode_mfma16"))
         rec = pq.reconstruct_batch(want)
         assert rec.tobytes() == orc.reconstruct_batch(q, want).tobytes()
     q0, xs = _km_inputs(1200, 2, 16, dsub, 1500 + dsub)
@@ -378,7 +390,7 @@ def test_device_resident_and_properties_at_scale(ra):
     x = torch.randn((n, M * dsub), device="cuda", dtype=torch.float32, generator=g)
     codes = pq.quantize_batch_device(x)
     torch.cuda.synchronize()
-    assert pq.last_encode_kernel() == "k_encode_mfma_lds3<vec4>"
+    assert pq.last_encode_kernel() == "k_encode_mfma16"
     # (1) sampled rows against the oracle: first / last 32k rows + a strided sample
     idx = torch.cat([torch.arange(0, 32768), torch.arange(n - 32768, n),
                      torch.arange(0, n, 97)]).cuda()
@@ -592,7 +604,7 @@ def test_shape_sweep_all_kernel_instantiations(ra):
         q = synth.normalish(5000 + i, (M, K, dsub))
         x = synth.normalish(6000 + i, (n, M * dsub))
         want = orc.quantize_batch(q, x)
-        for variant in (0, 2, 3):
+        for variant in (0, 2, 3, 4) + ((9,) if _has_mfma16(K, dsub) else ()):
             got = _pq(ra, q, variant=variant).quantize_batch(x)
             assert got.tobytes() == want.tobytes(), (M, K, dsub, n, variant)
     # device rows that start off the 16-byte grid (row stride not a multiple of 4 floats): the same
@@ -634,7 +646,7 @@ def test_cluster_assignments_entry_point(ra, kats):
                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
-    assert pq.last_encode_kernel().startswith("k_encode_mfma_lds3")
+    assert pq.last_encode_kernel() == "k_encode_mfma16"
     want = orc.cluster_assignments(cen, xd.cpu().numpy())
     assert out[:, 0].cpu().numpy().tolist() == want.tolist()
 
