@@ -271,8 +271,13 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float 
  * matrix tile (the auto choice for 2 floats, and for 4 floats from 48 subquantizers on), 8 = OPQ codebooks only: the
  * second-generation fused kernel (P block and codebook fragments in LDS; the auto choice for the shapes it is instantiated
  * for, PQHIP_EUNSUPPORTED otherwise), 9 = the LDS-atomic argmin on the 16x16x4 matrix instruction, four waves per
- * SIMD (the auto choice for >= 64 centroids and sub-vectors of 4, 8, .., 32 floats; PQHIP_EUNSUPPORTED otherwise) */
+ * SIMD (>= 64 centroids and sub-vectors of 4, 8, .., 32 floats, PQHIP_EUNSUPPORTED otherwise; the auto choice for more than
+ * 128 centroids and 12 .. 24 floats) */
 int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);
+/* process-wide: the OPQ rotation kernel where both exist (P block within LDS, 16-byte aligned rows): 0 = auto (the
+ * 16x16x4 form, k_rotate_pblock9, when the rows are gathered from the codebook inside the kernel -- OPQ reconstruct --
+ * and the 32x32x2 form, k_rotate_pblock8, for plain rotation), 8 / 9 force one of them                          */
+int32_t pqhip_set_rotation_variant(int32_t variant);
 /* name of the encode kernel the last device call on this codebook launched ("" if none)        */
 const char *pqhip_last_encode_kernel(const pqhip_codebook *cb);
 

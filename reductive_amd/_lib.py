@@ -116,6 +116,8 @@ def lib():
     L.pqhip_matrix_destroy.argtypes = [vp]
     L.pqhip_set_encode_variant.restype = i32
     L.pqhip_set_encode_variant.argtypes = [vp, i32]
+    L.pqhip_set_rotation_variant.restype = i32
+    L.pqhip_set_rotation_variant.argtypes = [i32]
     L.pqhip_last_encode_kernel.restype = ctypes.c_char_p
     L.pqhip_last_encode_kernel.argtypes = [vp]
     L.pqhip_selftest_mfma_chain.restype = i32
@@ -137,5 +139,5 @@ EXPORTS = [
     "pqhip_cluster_assignments_f32", "pqhip_kmeans_iterations_f32", "pqhip_kmeans_iterations_f32_dev",
     "pqhip_opq_train_step_f32_dev", "pqhip_at_dot_b_f32_dev", "pqhip_rotate_f32_dev",
     "pqhip_matrix_upload_f32", "pqhip_matrix_device_ptr", "pqhip_matrix_rows", "pqhip_matrix_destroy",
-    "pqhip_set_encode_variant", "pqhip_last_encode_kernel", "pqhip_selftest_mfma_chain",
+    "pqhip_set_encode_variant", "pqhip_set_rotation_variant", "pqhip_last_encode_kernel", "pqhip_selftest_mfma_chain",
 ]

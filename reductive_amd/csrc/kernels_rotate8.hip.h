@@ -78,10 +78,28 @@ __device__ __forceinline__ void rot8_burst(const float* plane_b, const float* pl
         const bool last = FULL ? (g == 7) : (g + 1 == ng);
         if (ROT8_ABLATE != 1 && ROT8_ABLATE != 4) rot8_read(nxt, last ? plane_next : plane_b + (g + 1) * 256);
         __builtin_amdgcn_sched_barrier(0);
+        if (ROT8_ABLATE == 5) {
+            // timing only: the same flop, registers and operands as 2 x v_mfma_f32_16x16x4_f32 per 32x32x2 instruction
+            auto pair16 = [](float av, float bv, f32x16& c, int idx) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int q4 = (2 * idx + u) & 3;
+                    f32x4 part = {c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]};
+                    part = __builtin_amdgcn_mfma_f32_16x16x4f32(u ? bv : av, u ? av : bv, part, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c[4 * q4 + e] = part[e];
+                }
+            };
+            pair16(cur.p0[0], xo[2 * g], c0, 0);
+            pair16(cur.p1[0], xo[2 * g], c1, 0);
+            pair16(cur.p0[1], xo[2 * g + 1], c0, 1);
+            pair16(cur.p1[1], xo[2 * g + 1], c1, 1);
+        } else {
         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.p0[0], xo[2 * g], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.p1[0], xo[2 * g], c1, 0, 0, 0);
         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.p0[1], xo[2 * g + 1], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.p1[1], xo[2 * g + 1], c1, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
     }

@@ -26,6 +26,7 @@
 #include "kernels_mfma.hip.h"
 #include "kernels_rotate.hip.h"
 #include "kernels_rotate8.hip.h"
+#include "kernels_rotate9.hip.h"
 #include "kernels_kmeans.hip.h"
 #include "kernels_adc.hip.h"
 #include "kernels_pair16.hip.h"
@@ -588,12 +589,18 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         // the VALU-argmin kernel keeps all T * DP/2 fragments in registers: small codebooks only
         const bool kind0_fits = cb->DP <= 32 && cb->T * (cb->DP / 2) <= 128 && code_bytes == 1;
         if (cb->variant == 2 && !kind0_fits) return PQHIP_EUNSUPPORTED;
-        // kind 3 (k_encode_mfma16: the same epilogue on v_mfma_f32_16x16x4_f32, four waves per SIMD) wherever it is
-        // instantiated: >= 64 centroids, every float of a sub-vector real and their number a multiple of 4
+        // kind 3 (k_encode_mfma16: the same epilogue on v_mfma_f32_16x16x4_f32, four waves per SIMD) is instantiated for
+        // >= 64 centroids and sub-vectors of 4, 8, .., 32 real floats; auto takes it where it wins on one box
+        // (tools/mfma16_shapes.sh, profiles/r3_encode_experiments.md): K > 128 and 12..24 floats -- +2 % at 12 / 24, +2.5 % at 20,
+        // +5 % at 16; shorter chains lose to the hybrid argmin of kind 2 (-15 % at 4 floats), 32 floats leave only 3 waves per
+        // SIMD (-2.4 %), and with 64 / 128 centroids the per-tile work (norms, row loads, code bytes) weighs more (-1 .. -18 %)
         static const bool no_mfma16 = getenv("PQHIP_DEBUG_NO_MFMA16") != nullptr;
         const bool kind3_fits = cb->T >= 2 && cb->DP <= 32 && cb->DP % 4 == 0 && cb->DP == cb->dsub && (code_bytes == 1 || code_bytes == 4);
+        // (u32 codes are the k-means assignment step, whose update kernels run beside it on a second stream: with four encode
+        // waves per SIMD the iteration was 2 % slower -- 20.4 vs 19.95 ms per 10 M rows -- so that caller stays on kind 2)
+        const bool kind3_auto = kind3_fits && cb->T == 8 && cb->DP >= 12 && cb->DP <= 24 && code_bytes == 1 && !no_mfma16;
         if (cb->variant == 9 && !kind3_fits) return PQHIP_EUNSUPPORTED;
-        const int kind = (cb->variant == 2 || tiny) ? 0 : ((cb->variant == 9 || (cb->variant == 0 && !no_mfma16)) && kind3_fits) ? 3 : 2;
+        const int kind = (cb->variant == 2 || tiny) ? 0 : (cb->variant == 9 || (cb->variant == 0 && kind3_auto)) ? 3 : 2;
         dim3 grid;
         if (kind >= 2) {
             // one workgroup = one subquantizer x 4 row streams (one per wave)
@@ -669,6 +676,8 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
 // out[n][d] = x[n][d] . Pm   on the device
 // ga != nullptr: the rows are gathered from the codebook inside the rotation kernel (Rot8Gather); returns
 // PQHIP_EUNSUPPORTED when the shape has no such kernel (the caller then gathers into a scratch buffer first).
+static std::atomic<int> g_rotation_variant{0};   // pqhip_set_rotation_variant: 0 auto, 8 / 9 force k_rotate_pblock8 / 9 (test knob)
+
 int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, int d, float* d_out,
                    int64_t o_rs, hipStream_t st, const Rot8Gather* ga = nullptr)
 {
@@ -684,7 +693,17 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         static const bool use_v8 = getenv("PQHIP_DEBUG_NO_GEMM8") == nullptr;
         const bool out_vec8 = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
         if (use_v8 && vec && out_vec8 && lds8 <= 160 * 1024) {
-            const int rows_per_wg = ga ? rot_rows_per_wg() / 12 * 8 : rot_rows_per_wg();   // 12 (gather form: 8) waves x 12 tiles of 32 rows
+            // v9 (the 16x16x4 form) is the default of the GATHER form only: 157 registers let it run 12 waves per workgroup
+            // where v8's gather needs 8 (OPQ reconstruct of 10 M codes: 16.4 vs 16.85 ms on one box); for plain rotation it
+            // executes 304 instead of 320 columns at d = 300 and holds a higher clock, but pays twice the vector instructions
+            // per k (operand transposes, addressing): 1.87 vs 1.83 ms per 1.18 M rows standalone, equal inside the OPQ chunk
+            // loop.  pqhip_set_rotation_variant(9) / (8) force one or the other (tests run every shape through both).
+            static const bool use_v9 = getenv("PQHIP_DEBUG_NO_GEMM9") == nullptr;
+            const int rv = g_rotation_variant.load(std::memory_order_relaxed);
+            const int nb9 = (d + 15) / 16;
+            const bool v9 = use_v9 && rv != 8 && (ga != nullptr || rv == 9) && nb9 >= 2 && (size_t)nb9 * 4096 <= 160 * 1024 &&
+                            (ga != nullptr || (double)rot_rows_per_wg() * (double)x_rs * 4.0 < 2147483648.0);   // 32-bit row offsets inside a row group
+            const int rows_per_wg = (ga && !v9) ? rot_rows_per_wg() / 12 * 8 : rot_rows_per_wg();   // 12 (v8's gather form: 8) waves x 12 tiles of 32 rows
             const int ncb = (d + 63) / 64;
             const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
             const int64_t rg_per_xcd = (n_rg + 7) / 8;
@@ -696,6 +715,25 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
                 PQCHK(stamp_buf.alloc(n_stamp * sizeof(unsigned long long)));
                 HIPCHK(hipMemsetAsync(stamp_buf.p, 0, n_stamp * sizeof(unsigned long long), st));
             }
+            // v9 (kernels_rotate9.hip.h): the same data flow on v_mfma_f32_16x16x4_f32 -- 16-wide column tiles (304 columns
+            // executed for d = 300 instead of 320) and the higher clock that shape holds under the power cap
+            if (v9) {
+                const size_t lds9 = (size_t)nb9 * 4096;
+                const bool splitk9 = d > kKC, odd9 = (nb9 & 1) != 0, tail9 = (d & 15) != 0;
+#define LAUNCH_ROT9G(S, O, T, G)                                                                                    \
+                do {                                                                                                \
+                    HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock9<S, O, T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                    hipLaunchKernelGGL((k_rotate_pblock9<S, O, T, G>), grid, dim3(768), lds9, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, \
+                                       rg_per_xcd, ga ? *ga : Rot8Gather{}, (unsigned long long*)stamp_buf.p);       \
+                } while (0)
+#define LAUNCH_ROT9(S, O, T) do { if (ga) LAUNCH_ROT9G(S, O, T, true); else LAUNCH_ROT9G(S, O, T, false); } while (0)
+                if (splitk9) { if (odd9) { if (tail9) LAUNCH_ROT9(true, true, true); else LAUNCH_ROT9(true, true, false); }
+                               else      { if (tail9) LAUNCH_ROT9(true, false, true); else LAUNCH_ROT9(true, false, false); } }
+                else         { if (odd9) { if (tail9) LAUNCH_ROT9(false, true, true); else LAUNCH_ROT9(false, true, false); }
+                               else      { if (tail9) LAUNCH_ROT9(false, false, true); else LAUNCH_ROT9(false, false, false); } }
+#undef LAUNCH_ROT9
+#undef LAUNCH_ROT9G
+            } else {
             // template facts: rule-2 split (d > 256), odd number of full 32-k bursts, partial last burst
             const bool splitk = d > kKC, odd = ((d >> 5) & 1) != 0, tail = (d & 31) != 0;
 #define LAUNCH_ROT8G(S, O, T, G)                                                                                    \
@@ -711,6 +749,7 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
                           else     { if (tail) LAUNCH_ROT8(false, false, true); else LAUNCH_ROT8(false, false, false); } }
 #undef LAUNCH_ROT8
 #undef LAUNCH_ROT8G
+            }
             HIPCHK(hipGetLastError());
             if (want_stamps) {   // diagnostics: synchronous summary on stderr
                 std::vector<unsigned long long> h(n_stamp);
@@ -728,7 +767,7 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
                     if (m > 0) { wgmax += m; ++wgs; }
                 }
                 if (tiles > 0)
-                    fprintf(stderr, "[pqhip] rotate v8 stamps: %zu waves, %.1f tiles/wave, tile %.0f cyc (first %.0f, last %.0f), P staging %.0f cyc/wave, wave life %.0f cyc (min %.0f, max %.0f; slowest wave of a workgroup %.0f), clock %.0f MHz\n",
+                    fprintf(stderr, "[pqhip] rotate v8/v9 stamps: %zu waves, %.1f tiles/wave, tile %.0f cyc (first %.0f, last %.0f), P staging %.0f cyc/wave, wave life %.0f cyc (min %.0f, max %.0f; slowest wave of a workgroup %.0f), clock %.0f MHz\n",
                             waves, tiles / waves, kc / tiles, first / waves, last / waves, ec / waves, cyc / waves, cmin, cmax, wgmax / wgs, rt > 0 ? cyc / rt * 100.0 : 0.0);
                 if (const char* f = getenv("PQHIP_DEBUG_ROT_STAMP_FILE")) {
                     if (FILE* fp = fopen(f, "ab")) { fwrite(h.data(), sizeof(unsigned long long), n_stamp, fp); fclose(fp); }
@@ -1779,6 +1818,13 @@ int64_t pqhip_codebook_quantized_len(const pqhip_codebook* cb) { return cb ? cb-
 int64_t pqhip_codebook_reconstructed_len(const pqhip_codebook* cb) { return cb ? cb->d : 0; }
 int64_t pqhip_codebook_n_centroids(const pqhip_codebook* cb) { return cb ? cb->K : 0; }
 int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && cb->has_proj; }
+
+int32_t pqhip_set_rotation_variant(int32_t variant)
+{
+    if (variant != 0 && variant != 8 && variant != 9) return PQHIP_EINVAL;
+    g_rotation_variant.store(variant, std::memory_order_relaxed);
+    return PQHIP_OK;
+}
 
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {

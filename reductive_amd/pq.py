@@ -302,6 +302,13 @@ def create_projection_matrix(instances, n_subquantizers):
     return P
 
 
+def set_rotation_variant(variant):
+    """test knob (include/pqhip.h: pqhip_set_rotation_variant), process-wide: 0 auto, 8 / 9 force that rotation kernel."""
+    rc = _lib.lib().pqhip_set_rotation_variant(variant)
+    if rc != _lib.OK:
+        raise _lib.PqHipError(rc, "pqhip_set_rotation_variant")
+
+
 def rotate(instances, projection, ctx=None):
     """`instances.dot(&projection)` (opq.rs:62, gaussian_opq.rs:55) on the GPU with the reference's
     summation order; CUDA float32 tensor [n, d] in, CUDA tensor out."""

@@ -134,7 +134,7 @@ def test_encode_matches_oracle(ra, shape, variant):
     if variant == 0 and K <= 256 and dsub <= 32:
         # auto: the VALU kernel for small codebooks with an instantiated sub-dimension, else an MFMA kernel
         assert pq.last_encode_kernel().startswith(("k_encode_mfma", "k_encode_smallk"))
-        assert (pq.last_encode_kernel() == "k_encode_mfma16") == _has_mfma16(K, dsub)
+        assert (pq.last_encode_kernel() == "k_encode_mfma16") == (_has_mfma16(K, dsub) and K > 128 and 12 <= dsub <= 24)
     if variant == 9:
         assert pq.last_encode_kernel() == "k_encode_mfma16"
     if variant == 4:
@@ -646,8 +646,16 @@ def test_cluster_assignments_entry_point(ra, kats):
                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
-    assert pq.last_encode_kernel() == "k_encode_mfma16"
+    assert pq.last_encode_kernel().startswith("k_encode_mfma_lds3")
     want = orc.cluster_assignments(cen, xd.cpu().numpy())
+    assert out[:, 0].cpu().numpy().tolist() == want.tolist()
+    pq.set_encode_variant(9)   # the 16x16x4 kernel with 32-bit codes
+    out.zero_()
+    rc = ra.lib().pqhip_quantize_batch_f32_dev(pq._cb(), 0, xd.data_ptr(), n, dim, out.data_ptr(), 4, 1,
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert pq.last_encode_kernel() == "k_encode_mfma16"
     assert out[:, 0].cpu().numpy().tolist() == want.tolist()
 
 
@@ -1071,25 +1079,34 @@ def test_resident_matrix_handle_feeds_the_training_entry_points(ra):
     L.pqhip_matrix_destroy(h)
 
 
-@pytest.mark.parametrize("d", [4, 20, 32, 40, 64, 72, 96, 100, 160, 256, 260, 288, 300, 320, 324, 352, 512, 600, 636, 640])
+@pytest.mark.parametrize("d", [4, 20, 32, 40, 48, 52, 64, 72, 80, 96, 100, 112, 160, 176, 240, 256, 260, 272, 288, 300, 320, 324, 336, 352,
+                               512, 600, 636, 640])
 def test_rotation_kernel_every_burst_structure(ra, d):
     """k_rotate_pblock8 is compiled for the eight combinations of (rule-2 split d > 256, odd number of full 32-k bursts,
     partial last burst); d = 4 .. 636 walks all of them plus the edges -- no full burst at all (d < 32), one burst, the
     largest d whose P block fits LDS (636) and the first one that falls back (640) -- with enough rows (two row groups,
     14 tiles for some waves, a ragged last tile) that the burst ring crosses tile and workgroup boundaries.  Bit-exact
-    against the oracle's rule-2 chains; non-contiguous rows and a wider output too."""
+    against the oracle's rule-2 chains; non-contiguous rows and a wider output too.
+    k_rotate_pblock9 (16x16x4; forced here, the default of the gather form) has its own eight combinations -- rule-2
+    split, odd number of 16-k bursts, d % 16 != 0 -- times one to four 16-column tiles in the last column block
+    (d = 272 / 336: one, 288: two, 300: three)."""
     import torch
     n = 4608 + 2 * 384 + 17
     x = synth.normalish(2100 + d, (n, d))
     P = synth.orthonormal(2101 + d, d) if d <= 320 else synth.normalish(2101 + d, (d, d)) * np.float32(0.05)
     want = orc.rotate(x, P)
-    got = ra.rotate(torch.from_numpy(x).cuda(), P).cpu().numpy()
-    assert got.tobytes() == want.tobytes()
-    if d % 4 == 0 and d >= 20:
-        wide = torch.zeros((n, d + 8), device="cuda")
-        wide[:, :d] = torch.from_numpy(x).cuda()
-        got2 = ra.rotate(wide[:, :d], P).cpu().numpy()
-        assert got2.tobytes() == want.tobytes()
+    try:
+        for variant in (0, 9, 8):   # auto (k_rotate_pblock8 for plain rotation), the 16x16x4 form, the 32x32x2 form
+            ra.set_rotation_variant(variant)
+            got = ra.rotate(torch.from_numpy(x).cuda(), P).cpu().numpy()
+            assert got.tobytes() == want.tobytes(), variant
+            if d % 4 == 0 and d >= 20:
+                wide = torch.zeros((n, d + 8), device="cuda")
+                wide[:, :d] = torch.from_numpy(x).cuda()
+                got2 = ra.rotate(wide[:, :d], P).cpu().numpy()
+                assert got2.tobytes() == want.tobytes(), variant
+    finally:
+        ra.set_rotation_variant(0)
 
 
 def test_rotate_entry_point_and_gaussian_opq(ra, kats):
