@@ -504,7 +504,7 @@ int32_t encode_grouped_dev(pqhip_codebook* cb, int slot, const float* d_x, int64
 // centroid norms and consults the device flag itself (captured k-means iterations).
 int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
                          void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st,
-                         const int* bad_flag = nullptr)
+                         const int* bad_flag = nullptr, bool beside_update = false)
 {
     if (n == 0) return PQHIP_OK;
     if ((cb->variant == 5 || cb->variant == 8) && !cb->has_proj) return PQHIP_EUNSUPPORTED;   // variants 5 / 8 = fused OPQ kernels only
@@ -596,9 +596,9 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         // SIMD (-2.4 %), and with 64 / 128 centroids the per-tile work (norms, row loads, code bytes) weighs more (-1 .. -18 %)
         static const bool no_mfma16 = getenv("PQHIP_DEBUG_NO_MFMA16") != nullptr;
         const bool kind3_fits = cb->T >= 2 && cb->DP <= 32 && cb->DP % 4 == 0 && cb->DP == cb->dsub && (code_bytes == 1 || code_bytes == 4);
-        // (u32 codes are the k-means assignment step, whose update kernels run beside it on a second stream: with four encode
+        // (beside_update: the k-means assignment step, whose update kernels run beside it on a second stream: with four encode
         // waves per SIMD the iteration was 2 % slower -- 20.4 vs 19.95 ms per 10 M rows -- so that caller stays on kind 2)
-        const bool kind3_auto = kind3_fits && cb->T == 8 && cb->DP >= 12 && cb->DP <= 24 && code_bytes == 1 && !no_mfma16;
+        const bool kind3_auto = kind3_fits && cb->T == 8 && cb->DP >= 12 && cb->DP <= 24 && !beside_update && !no_mfma16;
         if (cb->variant == 9 && !kind3_fits) return PQHIP_EUNSUPPORTED;
         const int kind = (cb->variant == 2 || tiny) ? 0 : (cb->variant == 9 || (cb->variant == 0 && kind3_auto)) ? 3 : 2;
         dim3 grid;
@@ -1119,7 +1119,7 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
             const int64_t r0 = (int64_t)w * wrows, rows = std::min<int64_t>(wrows, n - r0);
             const float* xw = d_x + r0 * x_rs;
             char* cw = (char*)codes.p + r0 * M * code_bytes;
-            PQCHK(encode_plain_dev(cb, slot, xw, rows, x_rs, cw, code_bytes, M, s_enc, bad_flag));
+            PQCHK(encode_plain_dev(cb, slot, xw, rows, x_rs, cw, code_bytes, M, s_enc, bad_flag, /*beside_update=*/true));
             if (s_enc != s_upd) {
                 HIPCHK(hipEventRecord(aux.ev[w], s_enc));
                 HIPCHK(hipStreamWaitEvent(s_upd, aux.ev[w], 0));

@@ -646,16 +646,16 @@ def test_cluster_assignments_entry_point(ra, kats):
                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
-    assert pq.last_encode_kernel().startswith("k_encode_mfma_lds3")
+    assert pq.last_encode_kernel() == "k_encode_mfma16"
     want = orc.cluster_assignments(cen, xd.cpu().numpy())
     assert out[:, 0].cpu().numpy().tolist() == want.tolist()
-    pq.set_encode_variant(9)   # the 16x16x4 kernel with 32-bit codes
+    pq.set_encode_variant(4)   # the 32x32x2 kernel with 32-bit codes
     out.zero_()
     rc = ra.lib().pqhip_quantize_batch_f32_dev(pq._cb(), 0, xd.data_ptr(), n, dim, out.data_ptr(), 4, 1,
                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
-    assert pq.last_encode_kernel() == "k_encode_mfma16"
+    assert pq.last_encode_kernel().startswith("k_encode_mfma_lds3")
     assert out[:, 0].cpu().numpy().tolist() == want.tolist()
 
 
