@@ -154,7 +154,7 @@ def test_encode_special_values(ra):
     x[151] *= np.float32(3e19)          # xx overflows to inf
     x[160] *= np.float32(1e-30)         # subnormal products
     want = orc.quantize_batch(q, x)
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 4, 9):
         got = _pq(ra, q, variant=variant).quantize_batch(x)
         assert got.tobytes() == want.tobytes(), variant
     # NaN / Inf / huge centroids: codebook leaves the fast path entirely
@@ -181,8 +181,40 @@ def test_encode_exact_and_near_ties(ra):
     x[192:256, :dsub] = big
     want = orc.quantize_batch(q, x)
     assert (want[:64, 0] == 7).all() and (want[64:128, 1] == 0).all()
-    for variant in (0, 1, 2, 3):
-        assert _pq(ra, q, variant=variant).quantize_batch(x).tobytes() == want.tobytes()
+    for variant in (0, 1, 2, 3, 4, 9):
+        assert _pq(ra, q, variant=variant).quantize_batch(x).tobytes() == want.tobytes(), variant
+
+
+@pytest.mark.parametrize("variant", [9, 4])
+def test_exact_path_rows_in_many_tiles_of_a_wave(ra, variant):
+    """Headline shape, 600,000 rows (18 row tiles per wave): rows for the exact path -- a NaN, +-Inf, a huge norm, a row
+    that sits exactly on a centroid (negative minimum after rounding), a -0 row -- sprinkled over every tile position,
+    whole tiles of them, and the ragged last tile.  k_encode_mfma16 only records such rows in its loop (a mask per tile,
+    a tile bit in a scalar register) and re-evaluates them after it; every code must equal the oracle's."""
+    import torch
+    M, K, dsub = 15, 256, 20
+    n = 600_000 + 13
+    q = synth.normalish(9301, (M, K, dsub))
+    x = synth.normalish(9302, (n, M * dsub))
+    rng = np.random.RandomState(9303)
+    for r in range(0, n, 97):
+        x[r, rng.randint(M * dsub)] = np.nan
+    for r in range(5, n, 101):
+        x[r, rng.randint(M * dsub)] = np.inf if r % 2 else -np.inf
+    for r in range(11, n, 89):
+        m = rng.randint(M)
+        x[r, m * dsub:(m + 1) * dsub] = q[m, rng.randint(K)]
+    for r in range(17, n, 103):
+        x[r] *= np.float32(3e19)
+    for r in range(23, n, 107):
+        x[r] = -0.0
+    x[32 * 1000:32 * 1003] = np.nan                       # three whole tiles
+    x[n - 5:] *= np.float32(1e19)                          # the ragged last tile
+    want = orc.quantize_batch(q, x, n_threads=16)
+    pq = _pq(ra, q, variant=variant)
+    got = pq.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert pq.last_encode_kernel() == ("k_encode_mfma16" if variant == 9 else "k_encode_mfma_lds3<vec4>")
+    assert got.tobytes() == want.tobytes()
 
 
 def test_reconstruct_exact_and_range_check(ra):
