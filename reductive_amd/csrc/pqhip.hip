@@ -178,8 +178,10 @@ private:
 // Staging of one host-resident call: two streams, two pinned/device buffer pairs (double buffering) and the host
 // threads that pack / drain rows.  A device slot owns kStageSets of them and LEASES one per call (round 2 held the
 // slot's mutex for the whole call, so two host callers on one device fully serialised -- VERDICT r2 weak #12, item 8):
-// two callers now overlap one's packing and PCIe copies with the other's kernels.
-constexpr int kStageSets = 2;
+// callers now overlap one's packing and PCIe copies with the others' kernels.  Four sets: the cache-concurrency test's four
+// host threads on one device ran at 0.56-0.68 of the serial time with two (half of them waited for a set), buffers and
+// packing threads of a set are created with its first lease, so an idle set costs nothing.
+constexpr int kStageSets = 4;
 struct StageSet {
     hipStream_t stream[2] = {nullptr, nullptr};
     Staging st[2];

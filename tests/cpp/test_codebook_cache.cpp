@@ -147,12 +147,13 @@ int main(int argc, char** argv)
         // ---- concurrency: 4 host threads x 2 distinct quantizers through ONE cache, 32 calls of
         // 2,048 rows each (a small batch is latency-bound -- launch, PCIe round trip, stream synchronisation -- so
         // concurrent callers CAN overlap; a large one is PCIe-bound and four of them cannot beat the link: at 8,192 rows
-        // the transfer is already 200 of a call's 345 us and the ratio moved between 0.6 and 0.86 from box to box).  The cache
+        // the transfer is already 200 of a call's 345 us and the ratio moved between 0.6 and 0.86 from box to box; at 2,048
+        // rows with two staging sets per device slot it was 0.56-0.63, half of the threads waiting for a set).  The cache
         // mutex covers lookups only and the device slot leases one of its staging sets per call: wall < 0.7 x the same
         // 64 calls made one after the other; every code equals the CPU oracle's.
         {
             CodebookCache<pqhip_codebook*> cache(4, real_create, real_destroy, ctx);
-            const int64_t M = 15, K = 256, dsub = 20, d = M * dsub, n = 2048;   // 2.4 MB per call: 50 us of PCIe beside ~150 us of latencies
+            const int64_t M = 15, K = 256, dsub = 20, d = M * dsub, n = 2048;   // 2.4 MB per call: 50 us of PCIe beside ~100 us of latencies
             const int CALLS = 32;
             std::vector<std::vector<float>> qs(2, std::vector<float>((size_t)(M * K * dsub)));
             unsigned s = 99;
