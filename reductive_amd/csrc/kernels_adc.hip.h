@@ -236,6 +236,47 @@ __global__ __launch_bounds__(1024) void k_adc_scan_u8_mq(const uint8_t* __restri
     if (bad) atomicOr(err, 1);
 }
 
+// 32-bit codes (K > 256) whose M x K table still fits LDS (M K <= 40,960 entries: K = 1,024 at M = 15 takes 60 KB, K = 2,048
+// 120 KB): the table in LDS as in the u8 kernel, one 1,024-thread workgroup per CU over a contiguous row range, a lane owns
+// whole rows and fetches its 4 M code bytes with 16-byte loads (rows are 4-byte aligned; consecutive lanes read consecutive
+// rows, so a wave's loads cover one contiguous span).  Same sum order, same range flag.
+__global__ __launch_bounds__(1024) void k_adc_scan_wide(const uint32_t* __restrict__ codes, int64_t n, int64_t c_rs,
+                                                        const float* __restrict__ lut, int M, int K,
+                                                        float* __restrict__ out, int64_t rows_per_wg, int* __restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) float lut_w[];   // [M][K]
+    for (int i = threadIdx.x; i < M * K; i += 1024) lut_w[i] = lut[i];
+    __syncthreads();
+    const int64_t row_begin = (int64_t)blockIdx.x * rows_per_wg;
+    int64_t row_end = row_begin + rows_per_wg;
+    if (row_end > n) row_end = n;
+    bool bad = false;
+    for (int64_t row = row_begin + threadIdx.x; row < row_end; row += 1024) {
+        const uint32_t* cr = codes + row * c_rs;
+        float s = 0.f;
+        const float* lm = lut_w;
+        int m = 0;
+        for (; m + 4 <= M; m += 4) {
+            const u32x4_u v = *reinterpret_cast<const u32x4_u*>(cr + m);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned c = v[e];
+                if (c >= (unsigned)K) { bad = true; c = 0; }
+                s = fadd(s, lm[c]);
+                lm += K;
+            }
+        }
+        for (; m < M; ++m) {
+            unsigned c = cr[m];
+            if (c >= (unsigned)K) { bad = true; c = 0; }
+            s = fadd(s, lm[c]);
+            lm += K;
+        }
+        out[row] = s;
+    }
+    if (bad) atomicOr(err, 1);
+}
+
 // any index width / any table size: tables read through L2, one thread per row.  No throughput claim.
 template <typename IdxT>
 __global__ __launch_bounds__(256) void k_adc_scan_any(const IdxT* __restrict__ codes, int64_t n, int64_t c_rs,

@@ -1978,6 +1978,13 @@ int32_t pqhip_adc_scan_f32_dev(pqhip_codebook* cb, int32_t slot, const float* d_
         float* out = d_out + q * o_rs;
         if (fast) {
             PQCHK(launch_adc_nv<1>(nv, (const uint8_t*)d_codes, n, c_rs, lut, M, K, out, cb->ctx->devs[slot]->n_cus, lds, err, st));
+        } else if (code_bytes == 4 && lds <= 160 * 1024 && getenv("PQHIP_DEBUG_ADC_ANY") == nullptr) {
+            // 32-bit codes, table within LDS (K <= 2,048 at M = 15): one 1,024-thread workgroup per CU, contiguous row ranges
+            const int n_cus = cb->ctx->devs[slot]->n_cus;
+            const int64_t rows_per_wg = round_up((n + n_cus - 1) / n_cus, 1024);
+            const unsigned grid = (unsigned)((n + rows_per_wg - 1) / rows_per_wg);
+            HIPCHK(hipFuncSetAttribute((const void*)k_adc_scan_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL(k_adc_scan_wide, dim3(grid), dim3(1024), lds, st, (const uint32_t*)d_codes, n, c_rs, lut, M, K, out, rows_per_wg, err);
         } else {
             const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 32);
             if (code_bytes == 1)

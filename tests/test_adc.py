@@ -174,6 +174,20 @@ def test_gpu_scan_wide_index_type_and_big_tables(ra):
     ti = pq.adc_tables_device(torch.from_numpy(x[:8]).cuda())
     dd = pq.adc_scan_device(torch.from_numpy(codes.astype(np.int32)).cuda(), ti).cpu().numpy()
     assert (dd.argmin(1) == np.arange(8)).all() or all(dd[i, i] == dd[i].min() for i in range(8))
+    # 32-bit codes with the table in LDS (k_adc_scan_wide: M K <= 40,960 entries) and beyond it (generic kernel); code rows
+    # inside a wider matrix (row stride > M, 4-byte aligned only); a code >= K raises the range flag
+    for (M2, K2, n2) in [(15, 1024, 70001), (15, 2048, 5003), (7, 300, 2049), (48, 1024, 3000)]:
+        g = torch.Generator(device="cuda").manual_seed(9610 + K2)
+        tab = torch.rand((3, M2, K2), device="cuda", generator=g)
+        wide = torch.randint(0, K2, (n2, M2 + 3), device="cuda", dtype=torch.int32, generator=g)
+        view = wide[:, 1:1 + M2]
+        pq2 = ra.Pq(None, synth.normalish(9611 + K2, (M2, K2, 2)))
+        got2 = pq2.adc_scan_device(view, tab, check=True).cpu().numpy()
+        want2 = orc.adc_scan(tab.cpu().numpy(), view.cpu().numpy().astype(np.uint32))
+        assert got2.tobytes() == want2.tobytes(), (M2, K2)
+        wide[n2 // 2, 2] = K2
+        with pytest.raises(ra.PanicError):
+            pq2.adc_scan_device(view, tab, check=True)
 
 
 @pytest.mark.gpu
