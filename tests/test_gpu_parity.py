@@ -652,6 +652,9 @@ def test_shape_sweep_all_kernel_instantiations(ra):
     assert _pq(ra, q).quantize_batch_device(view).cpu().numpy().tobytes() == got.cpu().numpy().tobytes()   # auto: k_encode_smallk
     want = orc.quantize_batch(q, view.cpu().numpy())
     assert got.cpu().numpy().tobytes() == want.tobytes()
+    pq9 = _pq(ra, q, variant=9)                                   # the 16x16x4 kernel loads single dwords: any 4-byte alignment
+    assert pq9.quantize_batch_device(view).cpu().numpy().tobytes() == want.tobytes()
+    assert pq9.last_encode_kernel() == "k_encode_mfma16"
 
 
 def test_cluster_assignments_entry_point(ra, kats):
