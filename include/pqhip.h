@@ -276,7 +276,8 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float 
 int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);
 /* process-wide: the OPQ rotation kernel where both exist (P block within LDS, 16-byte aligned rows): 0 = auto (the
  * 16x16x4 form, k_rotate_pblock9, when the rows are gathered from the codebook inside the kernel -- OPQ reconstruct --
- * and the 32x32x2 form, k_rotate_pblock8, for plain rotation), 8 / 9 force one of them                          */
+ * and for plain rotation where the 64-column blocks of the 32x32x2 form, k_rotate_pblock8, would execute >= 10 % more
+ * columns than 16-column tiles, e.g. d = 96, 144, 272, 400; k_rotate_pblock8 otherwise), 8 / 9 force one of them     */
 int32_t pqhip_set_rotation_variant(int32_t variant);
 /* name of the encode kernel the last device call on this codebook launched ("" if none)        */
 const char *pqhip_last_encode_kernel(const pqhip_codebook *cb);

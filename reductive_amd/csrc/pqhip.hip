@@ -695,15 +695,19 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         static const bool use_v8 = getenv("PQHIP_DEBUG_NO_GEMM8") == nullptr;
         const bool out_vec8 = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
         if (use_v8 && vec && out_vec8 && lds8 <= 160 * 1024) {
-            // v9 (the 16x16x4 form) is the default of the GATHER form only: 157 registers let it run 12 waves per workgroup
-            // where v8's gather needs 8 (OPQ reconstruct of 10 M codes: 16.4 vs 16.85 ms on one box); for plain rotation it
+            // v9 (the 16x16x4 form) is the default of the GATHER form: 157 registers let it run 12 waves per workgroup
+            // where v8's gather needs 8 (OPQ reconstruct of 10 M codes: 16.4 vs 16.85 ms on one box).  For plain rotation it
             // executes 304 instead of 320 columns at d = 300 and holds a higher clock, but pays twice the vector instructions
             // per k (operand transposes, addressing): 1.87 vs 1.83 ms per 1.18 M rows standalone, equal inside the OPQ chunk
-            // loop.  pqhip_set_rotation_variant(9) / (8) force one or the other (tests run every shape through both).
+            // loop -- so there it is taken only where v8 pads much (below).
+            // pqhip_set_rotation_variant(9) / (8) force one or the other (tests run every shape through both).
             static const bool use_v9 = getenv("PQHIP_DEBUG_NO_GEMM9") == nullptr;
             const int rv = g_rotation_variant.load(std::memory_order_relaxed);
             const int nb9 = (d + 15) / 16;
-            const bool v9 = use_v9 && rv != 8 && (ga != nullptr || rv == 9) && nb9 >= 2 && (size_t)nb9 * 4096 <= 160 * 1024 &&
+            // plain rotation: v9 where v8's 64-column blocks execute >= 10 % more columns than v9's 16-column tiles (d = 272: 320
+            // vs 272, 400: 448 vs 400, 96: 128 vs 96 ...): -5 .. -15 % there, within +-3 % elsewhere (tools/rot_variants.py)
+            const bool plain_v9 = 10 * 64 * ((d + 63) / 64) >= 11 * 16 * ((d + 15) / 16);
+            const bool v9 = use_v9 && rv != 8 && (ga != nullptr || rv == 9 || plain_v9) && nb9 >= 2 && (size_t)nb9 * 4096 <= 160 * 1024 &&
                             (ga != nullptr || (double)rot_rows_per_wg() * (double)x_rs * 4.0 < 2147483648.0);   // 32-bit row offsets inside a row group
             const int rows_per_wg = (ga && !v9) ? rot_rows_per_wg() / 12 * 8 : rot_rows_per_wg();   // 12 (v8's gather form: 8) waves x 12 tiles of 32 rows
             const int ncb = (d + 63) / 64;
