@@ -1962,6 +1962,7 @@ int32_t pqhip_adc_scan_f32_dev(pqhip_codebook* cb, int32_t slot, const float* d_
     // several queries per pass over the code matrix: 8 (or 4) tables interleaved in LDS when they fit
     // (PQHIP_DEBUG_ADC_SINGLE=1: one pass per query, the round-2 form, for A/B)
     static const bool mq_on = getenv("PQHIP_DEBUG_ADC_SINGLE") == nullptr;
+    static const bool adc_any = getenv("PQHIP_DEBUG_ADC_ANY") != nullptr;   // the generic kernel for 32-bit codes (A/B)
     int64_t q = 0;
     if (fast && mq_on) {
         const int n_cus = cb->ctx->devs[slot]->n_cus;
@@ -1982,7 +1983,7 @@ int32_t pqhip_adc_scan_f32_dev(pqhip_codebook* cb, int32_t slot, const float* d_
         float* out = d_out + q * o_rs;
         if (fast) {
             PQCHK(launch_adc_nv<1>(nv, (const uint8_t*)d_codes, n, c_rs, lut, M, K, out, cb->ctx->devs[slot]->n_cus, lds, err, st));
-        } else if (code_bytes == 4 && lds <= 160 * 1024 && getenv("PQHIP_DEBUG_ADC_ANY") == nullptr) {
+        } else if (code_bytes == 4 && lds <= 160 * 1024 && !adc_any) {
             // 32-bit codes, table within LDS (K <= 2,048 at M = 15): one 1,024-thread workgroup per CU, contiguous row ranges
             const int n_cus = cb->ctx->devs[slot]->n_cus;
             const int64_t rows_per_wg = round_up((n + n_cus - 1) / n_cus, 1024);
