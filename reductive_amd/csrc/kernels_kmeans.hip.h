@@ -212,36 +212,42 @@ __global__ __launch_bounds__(256) void k_km_segsum_w(const float* __restrict__ x
     float s = 0.f;
     if (!first && lane < dsub) s = acc[(int64_t)mk * dsub + lane];
 
-    unsigned r[PF];
-#pragma unroll
-    for (int t = 0; t < PF; ++t) {
-        const unsigned idx = beg + t * RPL + j;
-        r[t] = (active && idx < end) ? pm[idx] : 0u;
-    }
+    // Two batches in flight: while the PF * RPL rows of batch b are added (in row order, from the wave's LDS slab), the
+    // rows of batch b + 1 are on their way from HBM and the row ids of batch b + 2 from the permutation -- the walk of
+    // the largest cluster of a window is what the launch waits for, and with one batch in flight every batch paid a
+    // whole memory round trip in front of its adds (round 3: 0.54-0.73 ms per 512 k-row window, the k-means iteration
+    // waited for the update stream, not for the assignment).
     const unsigned per_iter = (unsigned)(PF * RPL);
-    for (unsigned i = beg; i < end; i += per_iter) {
-        f32x4 v4[PF];
-        float v1[PF];
+    auto ids = [&](unsigned (&r)[PF], unsigned i0) {
 #pragma unroll
         for (int t = 0; t < PF; ++t) {
-            const unsigned idx = i + t * RPL + j;
-            if (active && idx < end) {
-                const char* p = xc + (uint64_t)r[t] * rsb;
-                if (VEC) v4[t] = *reinterpret_cast<const f32x4*>(p);
-                else v1[t] = *reinterpret_cast<const float*>(p);
-            }
+            const unsigned idx = i0 + t * RPL + j;
+            r[t] = (active && idx < end) ? pm[idx] : 0u;     // (row 0 is a valid address; never added)
         }
+    };
+    auto fetch = [&](const unsigned (&r)[PF], f32x4 (&v4)[PF], float (&v1)[PF]) {
 #pragma unroll
-        for (int t = 0; t < PF; ++t) {  // row ids of the next iteration
-            const unsigned idx = i + per_iter + t * RPL + j;
-            r[t] = (active && idx < end) ? pm[idx] : 0u;
+        for (int t = 0; t < PF; ++t) {
+            const char* p = xc + (uint64_t)r[t] * rsb;
+            if (VEC) v4[t] = *reinterpret_cast<const f32x4*>(p);
+            else v1[t] = *reinterpret_cast<const float*>(p);
         }
+    };
+    unsigned r[PF];
+    f32x4 c4[PF], n4[PF];
+    float c1[PF], n1[PF];
+    ids(r, beg);
+    fetch(r, c4, c1);                       // batch 0
+    ids(r, beg + per_iter);                 // ids of batch 1
+    for (unsigned i = beg; i < end; i += per_iter) {
+        fetch(r, n4, n1);                   // batch b + 1 (clamped ids past the end: loads of row 0, never used)
+        ids(r, i + 2 * per_iter);           // ids of batch b + 2
 #pragma unroll
         for (int t = 0; t < PF; ++t) {
             if (active) {
                 float* d = buf + t * RPL * dsub + slot_off;
-                if (VEC) *reinterpret_cast<f32x4*>(d) = v4[t];
-                else *d = v1[t];
+                if (VEC) *reinterpret_cast<f32x4*>(d) = c4[t];
+                else *d = c1[t];
             }
         }
         const unsigned left = end - i;
@@ -251,6 +257,8 @@ __global__ __launch_bounds__(256) void k_km_segsum_w(const float* __restrict__ x
 #pragma unroll 8
             for (int jj = 0; jj < cnt; ++jj) s = fadd(s, col[jj * dsub]);
         }
+#pragma unroll
+        for (int t = 0; t < PF; ++t) { c4[t] = n4[t]; c1[t] = n1[t]; }
     }
     const unsigned cntk = (first ? 0u : tot_in[mk]) + (end - beg);
     if (lane < dsub) {
