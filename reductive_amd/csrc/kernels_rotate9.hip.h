@@ -25,7 +25,7 @@
 namespace pqhip {
 
 // the wave loop of one workgroup: CT column tiles of the staged P block
-template <int CT, bool SPLITK, bool ODD, bool TAIL, bool GATHER, int NWAVE>
+template <int CW, int CT, bool SPLITK, bool ODD, bool TAIL, bool GATHER, int NWAVE>
 __device__ __forceinline__ void rot9_run(const float* __restrict__ x, int64_t n, int64_t x_rs, int d, float* __restrict__ out,
                                          int64_t o_rs, int64_t wg_row0, int64_t wg_row1, int col0, const float* pl, const Rot8Gather& ga,
                                          unsigned long long* stamps, unsigned long long st_in)
@@ -35,7 +35,8 @@ __device__ __forceinline__ void rot9_run(const float* __restrict__ x, int64_t n,
     const int i16 = lane & 15, q = lane >> 4;
     const int nb = (d + 15) >> 4;                // 16-k bursts per tile (TAIL: the last one is partial)
     constexpr int KB = kKC / 16;                 // bursts per rule-2 block
-    const float* plane = pl + lane * 4;          // + 256 floats per k-group: the four tiles' A operands of this lane
+    typedef float pav_t __attribute__((ext_vector_type(CW)));
+    const float* plane = pl + lane * CW;         // + 64 CW floats per k-group: the block's CW tiles' A operands of this lane
 
     const int ntile = (int)((wg_row1 - wg_row0 + 31) >> 5);
     int cur_tile = wave;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void rot9_run(const float* __restrict__ x, int64_t n,
     unsigned po0 = row_off(row0, 0), po1 = row_off(row0, 1);
     load_burst(sa, po0, po1, 0);
     load_burst(sb, po0, po1, 1);
-    f32x4 pa = *reinterpret_cast<const f32x4*>(plane);          // A operands of the k-group about to issue
+    pav_t pa = *reinterpret_cast<const pav_t*>(plane);          // A operands of the k-group about to issue
     f32x4 t[2][CT];                                              // rule-2 block sums; between tiles: the finished tile on its way out
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -158,7 +159,7 @@ __device__ __forceinline__ void rot9_run(const float* __restrict__ x, int64_t n,
             if ((b) == 0 && pending) store_tile(t, prev_row0);                                         \
             _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
                 const bool last_ = (g == 3) && ((b) + 1 == nb);                                        \
-                const f32x4 pn_ = *reinterpret_cast<const f32x4*>(last_ ? plane : plane + (4 * (b) + g + 1) * 256); \
+                const pav_t pn_ = *reinterpret_cast<const pav_t*>(last_ ? plane : plane + (4 * (b) + g + 1) * (64 * CW)); \
                 __builtin_amdgcn_sched_barrier(0);                                                     \
                 _Pragma("unroll") for (int c = 0; c < CT; ++c) {                                       \
                     acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[c], xo_[0][g], acc[0][c], 0, 0, 0); \
@@ -249,7 +250,9 @@ __device__ __forceinline__ void rot9_run(const float* __restrict__ x, int64_t n,
 
 // ODD: odd number of 16-k bursts, TAIL: d % 16 != 0 (compile-time, so that the burst ring of a tile is one straight code path).
 // Launch geometry as v8: workgroup b -> XCD b % 8, column block (b / 8) % ncb, row group ((b / 8) / ncb) * 8 + xcd.
-template <bool SPLITK, bool ODD, bool TAIL, bool GATHER>
+// CW: column tiles per workgroup block -- 4 (64 columns, P image 4 KB per 16 k: d <= 640) or 2 (32 columns, 2 KB per 16 k:
+// d <= 1280, e.g. 768; each B operand then feeds half as many matrix instructions).
+template <int CW, bool SPLITK, bool ODD, bool TAIL, bool GATHER>
 __global__ __launch_bounds__(768, 3) void k_rotate_pblock9(const float* __restrict__ x, int64_t n, int64_t x_rs,
                                                            const float* __restrict__ Pm, int d, float* __restrict__ out,
                                                            int64_t o_rs, int rows_per_wg, int ncb, int64_t rg_per_xcd, Rot8Gather ga,
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock9(const float* __restri
     constexpr int NWAVE = 12;                    // also for the gather form: 157 registers, where v8's needed 221 and ran 8 waves
     constexpr int NT = 64 * NWAVE;
     extern __shared__ __attribute__((aligned(16))) float smem9[];
-    float* pl = smem9;                           // [4 ceil(d/16) k-groups][64 lanes (col i16, k q)][4 column tiles]
+    float* pl = smem9;                           // [4 ceil(d/16) k-groups][64 lanes (col i16, k q)][CW column tiles]
     const unsigned long long st_in = stamps ? __builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x;
 
@@ -268,18 +271,19 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock9(const float* __restri
     const int cb = (int)(qq % ncb);
     const int64_t rg_local = qq / ncb;
     const int64_t rg = rg_local * 8 + xcd;
-    const int col0 = cb * 64;
+    const int col0 = cb * 16 * CW;
 
     // stage the P block: Pm[k][col0 + 16 c + i16] -> image[(k >> 2) * 64 + (k & 3) * 16 + i16][c], zero beyond d in both directions
     {
         const int kpad = ((d + 15) >> 4) << 4;
-        const int total = kpad * 16;             // float4 per block: kpad rows x 16
+        constexpr int Q = 4 * CW;                // float4 per P row of the block
+        const int total = kpad * Q;
         for (int i0 = tid; i0 < total; i0 += NT * 2) {
             f32x4 v[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int idx = i0 + NT * u;
-                const int k = idx >> 4, c = col0 + 4 * (idx & 15);
+                const int k = idx / Q, c = col0 + 4 * (idx % Q);
                 v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (idx < total && k < d && c < d) v[u] = *reinterpret_cast<const f32x4*>(Pm + (int64_t)k * d + c);
             }
@@ -287,10 +291,10 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock9(const float* __restri
             for (int u = 0; u < 2; ++u) {
                 const int idx = i0 + NT * u;
                 if (idx < total) {
-                    const int k = idx >> 4, c4 = idx & 15;
-                    float* dst = pl + ((((k >> 2) << 6) + ((k & 3) << 4) + 4 * (c4 & 3)) << 2) + (c4 >> 2);
+                    const int k = idx / Q, c4 = idx % Q;
+                    float* dst = pl + ((((k >> 2) << 6) + ((k & 3) << 4) + 4 * (c4 & 3)) * CW) + (c4 >> 2);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dst[4 * e] = v[u][e];
+                    for (int e = 0; e < 4; ++e) dst[CW * e] = v[u][e];
                 }
             }
         }
@@ -301,12 +305,17 @@ __global__ __launch_bounds__(768, 3) void k_rotate_pblock9(const float* __restri
     if (wg_row0 >= n) return;
     int64_t wg_row1 = wg_row0 + rows_per_wg;
     if (wg_row1 > n) wg_row1 = n;
-    const int ct = (d - col0 >= 64) ? 4 : (d - col0 + 15) >> 4;   // column tiles with real columns (workgroup-uniform)
-    switch (ct) {
-    case 4: rot9_run<4, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in); break;
-    case 3: rot9_run<3, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in); break;
-    case 2: rot9_run<2, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in); break;
-    default: rot9_run<1, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in); break;
+    const int ct = (d - col0 >= 16 * CW) ? CW : (d - col0 + 15) >> 4;   // column tiles with real columns (workgroup-uniform)
+    if constexpr (CW == 4) {
+        switch (ct) {
+        case 4: rot9_run<4, 4, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in); break;
+        case 3: rot9_run<4, 3, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in); break;
+        case 2: rot9_run<4, 2, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in); break;
+        default: rot9_run<4, 1, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in); break;
+        }
+    } else {
+        if (ct == 2) rot9_run<2, 2, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in);
+        else rot9_run<2, 1, SPLITK, ODD, TAIL, GATHER, NWAVE>(x, n, x_rs, d, out, o_rs, wg_row0, wg_row1, col0, pl, ga, stamps, st_in);
     }
 }
 

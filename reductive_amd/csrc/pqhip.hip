@@ -694,7 +694,8 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
         const size_t lds8 = ((size_t)((d + 3) / 4) + 1) * 256 * sizeof(float);   // P image + one spare group (pre-reads past the last group)
         static const bool use_v8 = getenv("PQHIP_DEBUG_NO_GEMM8") == nullptr;
         const bool out_vec8 = (o_rs % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
-        if (use_v8 && vec && out_vec8 && lds8 <= 160 * 1024) {
+        const bool fits9 = (size_t)((d + 15) / 16) * 2048 <= 160 * 1024 && d >= 17;   // v9 with 32-column blocks reaches d = 1280
+        if (use_v8 && vec && out_vec8 && (lds8 <= 160 * 1024 || fits9)) {
             // v9 (the 16x16x4 form) is the default of the GATHER form: 157 registers let it run 12 waves per workgroup
             // where v8's gather needs 8 (OPQ reconstruct of 10 M codes: 16.4 vs 16.85 ms on one box).  For plain rotation it
             // executes 304 instead of 320 columns at d = 300 and holds a higher clock, but pays twice the vector instructions
@@ -707,10 +708,13 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
             // plain rotation: v9 where v8's 64-column blocks execute >= 10 % more columns than v9's 16-column tiles (d = 272: 320
             // vs 272, 400: 448 vs 400, 96: 128 vs 96 ...): -5 .. -15 % there, within +-3 % elsewhere (tools/rot_variants.py)
             const bool plain_v9 = 10 * 64 * ((d + 63) / 64) >= 11 * 16 * ((d + 15) / 16);
-            const bool v9 = use_v9 && rv != 8 && (ga != nullptr || rv == 9 || plain_v9) && nb9 >= 2 && (size_t)nb9 * 4096 <= 160 * 1024 &&
+            // d > 640: neither P block of 64 columns fits LDS; v9 then runs 32-column blocks (2 KB of image per 16 k: d <= 1280)
+            const bool narrow9 = (size_t)nb9 * 4096 > 160 * 1024;
+            const bool v9 = use_v9 && rv != 8 && (ga != nullptr || rv == 9 || plain_v9 || narrow9) && nb9 >= 2 && (size_t)nb9 * (narrow9 ? 2048 : 4096) <= 160 * 1024 &&
                             (ga != nullptr || (double)rot_rows_per_wg() * (double)x_rs * 4.0 < 2147483648.0);   // 32-bit row offsets inside a row group
             const int rows_per_wg = (ga && !v9) ? rot_rows_per_wg() / 12 * 8 : rot_rows_per_wg();   // 12 (v8's gather form: 8) waves x 12 tiles of 32 rows
-            const int ncb = (d + 63) / 64;
+            if (!v9 && lds8 > 160 * 1024) goto rot_fallback;   // (d > 636 with v9 switched off: the slab kernels below)
+            const int ncb = (v9 && narrow9) ? (d + 31) / 32 : (d + 63) / 64;
             const int64_t n_rg = (n + rows_per_wg - 1) / rows_per_wg;
             const int64_t rg_per_xcd = (n_rg + 7) / 8;
             const dim3 grid((unsigned)(rg_per_xcd * ncb * 8));
@@ -724,14 +728,15 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
             // v9 (kernels_rotate9.hip.h): the same data flow on v_mfma_f32_16x16x4_f32 -- 16-wide column tiles (304 columns
             // executed for d = 300 instead of 320) and the higher clock that shape holds under the power cap
             if (v9) {
-                const size_t lds9 = (size_t)nb9 * 4096;
+                const size_t lds9 = (size_t)nb9 * (narrow9 ? 2048 : 4096);
                 const bool splitk9 = d > kKC, odd9 = (nb9 & 1) != 0, tail9 = (d & 15) != 0;
-#define LAUNCH_ROT9G(S, O, T, G)                                                                                    \
+#define LAUNCH_ROT9W(W, S, O, T, G)                                                                                 \
                 do {                                                                                                \
-                    HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock9<S, O, T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                    hipLaunchKernelGGL((k_rotate_pblock9<S, O, T, G>), grid, dim3(768), lds9, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, \
+                    HIPCHK(hipFuncSetAttribute((const void*)k_rotate_pblock9<W, S, O, T, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                    hipLaunchKernelGGL((k_rotate_pblock9<W, S, O, T, G>), grid, dim3(768), lds9, st, d_x, n, x_rs, Pm, d, d_out, o_rs, rows_per_wg, ncb, \
                                        rg_per_xcd, ga ? *ga : Rot8Gather{}, (unsigned long long*)stamp_buf.p);       \
                 } while (0)
+#define LAUNCH_ROT9G(S, O, T, G) do { if (narrow9) LAUNCH_ROT9W(2, S, O, T, G); else LAUNCH_ROT9W(4, S, O, T, G); } while (0)
 #define LAUNCH_ROT9(S, O, T) do { if (ga) LAUNCH_ROT9G(S, O, T, true); else LAUNCH_ROT9G(S, O, T, false); } while (0)
                 if (splitk9) { if (odd9) { if (tail9) LAUNCH_ROT9(true, true, true); else LAUNCH_ROT9(true, true, false); }
                                else      { if (tail9) LAUNCH_ROT9(true, false, true); else LAUNCH_ROT9(true, false, false); } }
@@ -739,6 +744,7 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
                                else      { if (tail9) LAUNCH_ROT9(false, false, true); else LAUNCH_ROT9(false, false, false); } }
 #undef LAUNCH_ROT9
 #undef LAUNCH_ROT9G
+#undef LAUNCH_ROT9W
             } else {
             // template facts: rule-2 split (d > 256), odd number of full 32-k bursts, partial last burst
             const bool splitk = d > kKC, odd = ((d >> 5) & 1) != 0, tail = (d & 31) != 0;
@@ -782,7 +788,8 @@ int32_t rotate_dev(const float* d_x, int64_t n, int64_t x_rs, const float* Pm, i
             return PQHIP_OK;
         }
     }
-    if (ga) return PQHIP_EUNSUPPORTED;           // only v8 gathers inside the kernel
+rot_fallback:
+    if (ga) return PQHIP_EUNSUPPORTED;           // only v8 / v9 gather inside the kernel
     {
         // v6: as v5 with three waves per SIMD (12-wave workgroups, 16-k slabs)
         const size_t lds6 = ((size_t)((d + 3) / 4) * 256 + (size_t)12 * 2 * 32 * 20) * sizeof(float);

@@ -1115,7 +1115,7 @@ def test_resident_matrix_handle_feeds_the_training_entry_points(ra):
 
 
 @pytest.mark.parametrize("d", [4, 20, 32, 40, 48, 52, 64, 72, 80, 96, 100, 112, 160, 176, 240, 256, 260, 272, 288, 300, 320, 324, 336, 352,
-                               512, 600, 636, 640])
+                               512, 600, 636, 640, 704, 768, 1024, 1280, 1284])
 def test_rotation_kernel_every_burst_structure(ra, d):
     """k_rotate_pblock8 is compiled for the eight combinations of (rule-2 split d > 256, odd number of full 32-k bursts,
     partial last burst); d = 4 .. 636 walks all of them plus the edges -- no full burst at all (d < 32), one burst, the
@@ -1124,7 +1124,8 @@ def test_rotation_kernel_every_burst_structure(ra, d):
     against the oracle's rule-2 chains; non-contiguous rows and a wider output too.
     k_rotate_pblock9 (16x16x4; forced here, the default of the gather form) has its own eight combinations -- rule-2
     split, odd number of 16-k bursts, d % 16 != 0 -- times one to four 16-column tiles in the last column block
-    (d = 272 / 336: one, 288: two, 300: three)."""
+    (d = 272 / 336: one, 288: two, 300: three); beyond d = 640 it runs 32-column blocks (auto there: 704, 768, 1024, 1280;
+    1284 is the first d that falls back to the slab kernel)."""
     import torch
     n = 4608 + 2 * 384 + 17
     x = synth.normalish(2100 + d, (n, d))

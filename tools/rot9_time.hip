@@ -27,7 +27,7 @@ int main(int argc, char** argv)
     const size_t lds = (size_t)((d + 15) / 16) * 4096;
     const size_t n_stamp = (size_t)grid.x * 12 * 8;
     CK(hipMalloc(&st, n_stamp * 8));
-    auto k = k_rotate_pblock9<true, true, true, false>;
+    auto k = k_rotate_pblock9<4, true, true, true, false>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     double total = 0; float last = 0;
