@@ -9,7 +9,8 @@ namespace pqhip {
 // KIND 0: k_encode_mfma (VALU argmin epilogue); KIND 2: k_encode_mfma_lds3 (LDS-atomic argmin,
 // A fragments in LDS, 3 waves/SIMD); KIND 3: k_encode_mfma16 (same epilogue on the 16x16x4 matrix instruction, 4 waves/SIMD;
 // T in {2, 4, 8}, DPSET 0, dsub == DP only).  DPSET 0: DP in {4, 8, .., 32}; DPSET 1: DP in {2, 6, .., 30};
-// DPSET 2 (KIND 2 only): wide sub-vectors, DP in {40, 48, 56, 64}.
+// DPSET 2 (KIND 2 only): wide sub-vectors, DP in {40, 48, 56, 64} and, one wave per SIMD with the operands spread over both
+// register files, {80, 96, 112, 128}.
 // Returns false when (T, DP, code_bytes) has no instantiation: u8 codes for both kinds, u32 codes
 // (k-means assignment step / wide index types) for KIND 2 only.
 template <int KIND, int T, int DPSET>
@@ -37,7 +38,7 @@ inline bool launch_encode_mfma(int kind, int T, int DP, bool vec, int code_bytes
     if (kind == 2 && T == TT && DP > 32) return launch_encode_mfma_t<2, TT, 2>(DP, vec, code_bytes, a, grid, st);
     PQHIP_WIDE(1) PQHIP_WIDE(2) PQHIP_WIDE(4) PQHIP_WIDE(8)
 #undef PQHIP_WIDE
-    if (DP > 32) return false;
+    if (DP > 32) return false;   // (beyond 128: no matrix-core kernel)
 #define PQHIP_16(TT) \
     if (kind == 3 && T == TT) return (DP % 4 == 0) ? launch_encode_mfma_t<3, TT, 0>(DP, vec, code_bytes, a, grid, st) : false;
     PQHIP_16(2) PQHIP_16(4) PQHIP_16(8)

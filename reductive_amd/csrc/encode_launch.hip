@@ -3,7 +3,7 @@
 // v_mfma_f32_16x16x4_f32 with four waves per SIMD (kernels_mfma16.hip.h; the default where it is instantiated:
 // T >= 2, DP = dsub = 0 (mod 4), DPSET 0 only).
 // PQ_DPSET 0: padded sub-dimension DP = 0 (mod 4), 1: DP = 2 (mod 4), 2: wide sub-vectors DP in
-// {40, 48, 56, 64} (default kernel only).
+// {40, 48, 56, 64, 80, 96, 112, 128} (default kernel only).
 #include "encode_launch.h"
 #include <cstdlib>
 #include "kernels_mfma_lds.hip.h"
@@ -89,6 +89,10 @@ bool launch_encode_mfma_t(int DP, bool vec, int code_bytes, const EncodeArgs& a,
             case 48: return launch_vec<KIND, T, 48>(vec, code_bytes, a, grid, st);
             case 56: return launch_vec<KIND, T, 56>(vec, code_bytes, a, grid, st);
             case 64: return launch_vec<KIND, T, 64>(vec, code_bytes, a, grid, st);
+            case 80: return launch_vec<KIND, T, 80>(vec, code_bytes, a, grid, st);
+            case 96: return launch_vec<KIND, T, 96>(vec, code_bytes, a, grid, st);
+            case 112: return launch_vec<KIND, T, 112>(vec, code_bytes, a, grid, st);
+            case 128: return launch_vec<KIND, T, 128>(vec, code_bytes, a, grid, st);
             default: return false;
             }
         } else {

@@ -975,9 +975,10 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
     // MFMA geometry: K <= 256 padded to {1,2,4,8} tiles of 32; dsub <= 32 padded to an even
     // number of k (one MFMA consumes two); A fragments must fit (T * DP/2 <= 128).
     int T = 0, DP = 0, groups = 1;
-    if (K <= 65536 && dsub <= 64) {
-        // sub-dimension: even padding up to 32, multiples of 8 for wide sub-vectors (33..64)
-        DP = dsub <= 32 ? (int)round_up(dsub, 2) : (int)round_up(dsub, 8);
+    if (K <= 65536 && dsub <= 128) {
+        // sub-dimension: even padding up to 32, multiples of 8 for wide sub-vectors (33..64), of 16 for 65..128 (one chain
+        // of up to 128 k: still a single rule-2 block; the scalar kernel those shapes ran on reached 5e5 vectors/s)
+        DP = dsub <= 32 ? (int)round_up(dsub, 2) : dsub <= 64 ? (int)round_up(dsub, 8) : (int)round_up(dsub, 16);
         if (K <= 256) {
             const int tiles = (int)((K + 31) / 32);
             T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : tiles <= 4 ? 4 : 8;

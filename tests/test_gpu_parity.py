@@ -105,7 +105,8 @@ SHAPES = [  # n, M, K, dsub
     (300, 5, 40, 7),        # odd dsub, K not a multiple of 32
     (257, 3, 200, 32),      # largest resident fragment set
     (100, 4, 300, 6),       # K > 256 -> wider index type, anchor kernel
-    (64, 2, 64, 40),        # dsub > 32 -> anchor kernel
+    (64, 2, 64, 40),        # wide sub-vectors
+    (50, 2, 40, 130),       # dsub > 128 -> anchor kernel
     (33, 1, 1, 5),          # K = 1
     (1, 15, 256, 20),       # single row
 ]
@@ -325,10 +326,10 @@ def test_more_than_256_centroids_on_the_matrix_path(ra, shape):
     assert gq.tobytes() == wq.tobytes() and gl.tobytes() == wl.tobytes()
 
 
-@pytest.mark.parametrize("dsub", [33, 36, 40, 41, 47, 48, 50, 56, 57, 60, 63, 64])
+@pytest.mark.parametrize("dsub", [33, 36, 40, 41, 47, 48, 50, 56, 57, 60, 63, 64, 65, 72, 80, 81, 96, 100, 112, 127, 128])
 def test_wide_subvectors_on_the_matrix_path(ra, dsub):
-    """32 < dsub <= 64: the default kernel with one wave per SIMD and 20..32-MFMA chains (DP = 40,
-    48, 56, 64 with zero k-padding) -- codes equal the oracle's, K <= 256 and grouped K > 256,
+    """32 < dsub <= 128: the default kernel with one wave per SIMD and 20..64-MFMA chains (DP = 40,
+    48, 56, 64, 80, 96, 112, 128 with zero k-padding) -- codes equal the oracle's, K <= 256 and grouped K > 256,
     special values included; the k-means step on top of it."""
     for (n, M, K) in [(777, 3, 256), (300, 2, 37), (500, 2, 300)]:
         q = synth.normalish(1400 + dsub + K, (M, K, dsub))
