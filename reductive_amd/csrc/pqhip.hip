@@ -1311,7 +1311,12 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     // wide stores, so neither the row stride nor the base address matters); a chunk is filled with
     // one, two or four codebook accesses depending on how sub-vectors line up with it
     const bool vec = d % 4 == 0;
-    const int gsz = !vec ? 1 : (cb->dsub % 4 == 0) ? 4 : (cb->dsub % 2 == 0) ? 2 : 1;
+    // (gsz 0, odd sub-vectors of >= 5 floats: one unaligned 16-byte access per chunk that lies inside a sub-vector,
+    // element-wise across a boundary -- 10 M x 300: dsub 15 4.10 -> 3.50 ms, dsub 5 5.30 -> 4.59 ms; even sub-vectors keep
+    // two aligned 8-byte accesses per chunk, which is faster there: dsub 30 2.15 vs 3.09 ms.
+    // PQHIP_DEBUG_REC_ELEMWISE=1: the per-element form, for A/B)
+    static const bool rec_elemwise = getenv("PQHIP_DEBUG_REC_ELEMWISE") != nullptr;
+    const int gsz = !vec ? 1 : (cb->dsub % 4 == 0) ? 4 : (cb->dsub % 2 == 0) ? 2 : (cb->dsub > 4 && !rec_elemwise) ? 0 : 1;
     const int cpr = vec ? d / 4 : d;
     // rows per block: as many as keep rows*cpr < 2^16 (so that L / cpr == umulhi(L, ceil(2^32 / cpr))
     // exactly: the error term L * (inv * cpr - 2^32) stays below 2^32) and the block's codes within
@@ -1345,7 +1350,7 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     // PQHIP_DEBUG_REC_WGS overrides the per-CU count.
     static const int rec_wgs_per_cu = [] { const char* e = getenv("PQHIP_DEBUG_REC_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
     const int64_t nblocks = (n + rows_per_block - 1) / rows_per_block;
-    const size_t lds = (((size_t)cpr * (vec ? 4 / gsz : 1) * sizeof(int) + 15) & ~(size_t)15) +
+    const size_t lds = (((size_t)cpr * ((vec && gsz) ? 4 / gsz : 1) * sizeof(int) + 15) & ~(size_t)15) +
                        (((size_t)2 * rows_per_block * cb->M * code_bytes + 15) & ~(size_t)15) +
                        (sel_rows ? (size_t)2 * rows_per_block * sizeof(float) : 0);
 #define LAUNCH_REC3(IDX, V, GG, NEE)                                                              \
@@ -1374,6 +1379,7 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     do {                                                                                          \
         if (!vec) LAUNCH_REC2(IDX, 1, 1);                                                         \
         else if (gsz == 4) LAUNCH_REC2(IDX, 4, 4);                                                \
+        else if (gsz == 0) LAUNCH_REC2(IDX, 4, 0);                                                \
         else if (gsz == 2) LAUNCH_REC2(IDX, 4, 2);                                                \
         else LAUNCH_REC2(IDX, 4, 1);                                                              \
     } while (0)
