@@ -197,7 +197,7 @@ int32_t pqhip_cluster_assignments_f32(pqhip_ctx *ctx, const float *centroids, in
  * row order, f32 counts, IEEE division, one sequential fold for the loss); empty clusters become
  * zero vectors as in kmeans.rs:180-197.  The instances stay resident on one device for all
  * iterations (host entry point: the first device of the context).  Limits: K <= 16384,
- * n_rows <= 2^31; sub-vectors wider than 128 floats use the slow anchor kernel for the assignment
+ * n_rows <= 2^31; sub-vectors wider than 256 floats use the slow anchor kernel for the assignment
  * step.  Both calls return synchronised.
  */
 int32_t pqhip_kmeans_iterations_f32(pqhip_ctx *ctx, float *quantizers, int64_t n_subquantizers,

@@ -1,0 +1,137 @@
+// kernels_mfma_wide.hip.h -- PQ encode for sub-vectors of 129 .. 256 floats (d = 768 with M = 4, d = 1024 with M = 4 ...,
+// k-means over whole vectors of up to 256 dimensions): the shapes that still ran the scalar anchor kernel (4-16e5 vectors/s).
+//
+// One rule-2 chain is at most 256 k long, so these sub-vectors are still ONE fmaf chain per (row, centroid) -- up to 128
+// chained v_mfma_f32_32x32x2_f32 per 32 x 32 tile.  What does not carry over from k_encode_mfma_lds3 is its register budget
+// (operands of this tile, of the next tile and the next chain's fragments: 2.5 DP registers) and its LDS budget (fragments of
+// 256 centroids: DP KB).  So this kernel is deliberately plain:
+//   * a codebook is presented in GROUPS of 32 T <= 128 centroids (the grouped machinery of K > 256: one 64-bit key
+//     {ordered distance, global index} per (row, group), k_merge_keys takes the minimum), T <= 4 tiles = 128 KB of fragments;
+//   * no software pipeline: a wave loads its 32-row tile (lane (row j, half h) fetches one half of the sub-vector, one
+//     v_permlane32_swap per register pair makes the B operands, as in the default kernel), waits, runs T chains with the
+//     fragments read from LDS as they are needed, and keeps the running minimum key in registers -- a chain is 5,000-8,000
+//     cycles long, the 48 vector instructions of a lane-local argmin and the exposed load are a few per cent of it;
+//   * ||x||^2 comes from a pre-pass (k_row_norms: rule 1 needs the elements of a sub-vector in ndarray's order, which the
+//     split operand layout does not keep for a run-time length), 4 M bytes per row.
+// Exact path and key format as in k_encode_mfma_lds3 (KEYS mode): a negative or non-finite minimum or a huge norm sends the
+// row to encode_rows_slow_v, which writes the full-K key.
+#pragma once
+#include "kernels_mfma.hip.h"
+
+namespace pqhip {
+
+// xx[row][m] = unrolled_dot(x[row, m dsub ..], same) -- rule 1, any dsub; one thread per (row, m)
+__global__ __launch_bounds__(256) void k_row_norms(const float* __restrict__ x, int64_t n, int64_t x_rs, int M, int dsub,
+                                                   float* __restrict__ xx)
+{
+    const int64_t total = n * M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / M;
+        const int m = (int)(i - row * M);
+        xx[i] = norm_unrolled_global(x + row * x_rs + (int64_t)m * dsub, dsub);
+    }
+}
+
+// EncodeArgs as for the grouped default kernel: M = M_real * groups virtual subquantizers of T tiles, out = u64 keys
+// [n][o_rs], k_pad = 32 T groups; `xx` = the pre-pass norms [n][M_real].
+template <int T, int DP>
+__global__ __launch_bounds__(256, 1) void k_encode_mfma_wide(EncodeArgs a, const float* __restrict__ xx)
+{
+    static_assert(T >= 1 && T <= 4 && DP % 16 == 0 && DP > 128 && DP <= 256, "no such instantiation");
+    constexpr int S = DP / 2;                 // matrix instructions per chain
+    extern __shared__ __attribute__((aligned(16))) float wide_s[];
+    float* afrag_s = wide_s;                  // [T][S][64]
+    float* cc_s = wide_s + T * S * 64;        // [T * 32]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t q = b >> 3;
+    const int64_t g_local = q / a.M;
+    const int m = (int)(q - g_local * a.M);           // virtual subquantizer: (m_real, group)
+    const int64_t group = g_local * 8 + xcd;
+    const bool wg_active = (g_local < a.chunks_per_xcd) && (group < a.n_chunks);
+    if (wg_active) {
+        const float* fp = a.frags + (int64_t)m * T * S * 64;
+        for (int i = threadIdx.x; i < T * S * 64; i += 256) afrag_s[i] = fp[i];
+        const float* ccm = a.cc + (int64_t)m * T * 32;
+        for (int i = threadIdx.x; i < T * 32; i += 256) cc_s[i] = ccm[i];
+    }
+    __syncthreads();
+    const int64_t row_begin = (group * 4 + wave) * a.rows_per_item;
+    if (!wg_active || row_begin >= a.n) return;
+    int64_t row_end = row_begin + a.rows_per_item;
+    if (row_end > a.n) row_end = a.n;
+    const int m_real = m / a.groups, grp = m - m_real * a.groups;
+    const int Mreal = a.M / a.groups;
+    const float* xcol = a.x + (int64_t)m_real * a.dsub + h * (DP / 2);
+    const int cnt = h ? (a.dsub > DP / 2 ? a.dsub - DP / 2 : 0) : (a.dsub < DP / 2 ? a.dsub : DP / 2);   // real floats of this half
+
+    int lo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lo[r] = (r & 3) + 8 * (r >> 2) + 4 * h;       // centroid of accumulator register r inside a tile
+
+    for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
+        const int64_t row = (row0 + j < a.n) ? row0 + j : a.n - 1;              // rows past the end: clamped, never stored
+        float bop[S];
+        {
+            float v[DP / 2];
+            load_row_floats_rt<DP / 2>(xcol + row * a.x_rs, cnt, v);
+#pragma unroll
+            for (int i = 0; i < DP / 4; ++i) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * i]), __float_as_uint(v[2 * i + 1]), false, false);
+                bop[i] = __uint_as_float(r[0]);             // half 0: x[2i],        half 1: x[2i + 1]
+                bop[DP / 4 + i] = __uint_as_float(r[1]);    // half 0: x[DP/2 + 2i], half 1: x[DP/2 + 2i + 1]
+            }
+        }
+        const float xr = xx[row * Mreal + m_real];
+        const f32x2 xx2 = {xr, xr};
+        long long best = 0x7fffffffffffffffll;
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* af = afrag_s + (t * S) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s * 64], bop[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(&cc_s[32 * t + 8 * g + 4 * h]);
+                const f32x2 c01 = {c4[0], c4[1]}, c23 = {c4[2], c4[3]};
+                f32x2 t01, t23;
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t01) : "v"(xx2), "v"(c01));
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t23) : "v"(xx2), "v"(c23));
+                const float tt[4] = {t01[0], t01[1], t23[0], t23[1]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = ffma(acc[4 * g + e], -2.0f, tt[e]);
+                    const long long key = ((long long)__float_as_int(d) << 32) | (long long)(unsigned)(32 * t + lo[4 * g + e]);
+                    best = key < best ? key : best;          // signed order of {bits(d), index} = (distance, index) for d >= 0
+                }
+            }
+        }
+        // the other half's candidate (centroids +4..7 of every group of 8), lower key wins
+        {
+            const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)(best >> 32), (unsigned)(best >> 32), false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)best, (unsigned)best, false, false);
+            const long long other = ((long long)(int)(h ? s0[0] : s0[1]) << 32) | (long long)(h ? s1[0] : s1[1]);
+            best = other < best ? other : best;
+        }
+        const float bd = __int_as_float((int)(best >> 32));
+        const bool valid = row0 + j < a.n;
+        // exact path: a negative / non-finite minimum (a NaN's bits sort above every finite value only when positive), a huge
+        // or non-finite norm
+        const bool odd_row = !(bd >= 0.f) || !(bd < __builtin_inff()) || !(xr < kBigNorm);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && odd_row);
+        const unsigned need = (unsigned)(bal | (bal >> 32));
+        if (h == 0 && valid && !((need >> j) & 1u)) {
+            const unsigned gidx = (unsigned)best + 32u * (unsigned)T * (unsigned)grp;
+            reinterpret_cast<unsigned long long*>(a.out)[(row0 + j) * a.o_rs + m] = ((unsigned long long)ord_key(bd) << 32) | (unsigned long long)gidx;
+        }
+        if (need) encode_rows_slow_v<unsigned long long>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, a.groups, m, row0, need);
+    }
+}
+
+}  // namespace pqhip

@@ -34,6 +34,7 @@
 #include "opq_fused_launch.h"
 #include "opq_fused2_launch.h"
 #include "smallk_launch.h"
+#include "wide_launch.h"
 
 using namespace pqhip;
 
@@ -276,6 +277,7 @@ struct pqhip_codebook {
     bool has_proj = false;
     // MFMA encode geometry (0 = shape not covered, anchor kernel is used)
     int T = 0, DP = 0, k_pad = 0;
+    bool wide = false;      // 128 < dsub <= 256: groups of 32 T <= 128 centroids through k_encode_mfma_wide (kernels_mfma_wide.hip.h)
     int KP = 0;             // small codebooks (K <= 64, instantiated dsub): padded centroid count of the VALU kernel
     bool pair16 = false;    // K <= 16 and dsub in {2, 4, 8, 16}: the two-subquantizers-per-tile kernel applies
     int groups = 1;         // K > 256: groups of 256 centroids (8 tiles each) merged through 64-bit keys
@@ -501,6 +503,50 @@ int32_t encode_grouped_dev(pqhip_codebook* cb, int slot, const float* d_x, int64
     return PQHIP_OK;
 }
 
+// 128 < dsub <= 256 (kernels_mfma_wide.hip.h): squared norms by a pre-pass, one 64-bit key per (row, group of <= 128
+// centroids) from the matrix-core kernel, k_merge_keys -> codes.  Keys and norms live in one leased scratch buffer, rows are
+// chunked so that it stays <= 1 GiB.
+int32_t encode_wide_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,
+                        void* d_codes, int code_bytes, int64_t o_rs, hipStream_t st)
+{
+    CodebookDev& cd = cb->dev[slot];
+    const int64_t Mv = cb->M * cb->groups;
+    const int64_t per_row = Mv * 8 + cb->M * 4;
+    const int64_t chunk = std::min<int64_t>(n, std::max<int64_t>(4096, (1ll << 30) / per_row));
+    ScratchLease buf(cb, slot, st);
+    PQCHK(buf.acquire((size_t)chunk * per_row));
+    unsigned long long* keys = (unsigned long long*)buf.ptr();
+    float* xx = (float*)(keys + chunk * Mv);
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t rows = std::min<int64_t>(chunk, n - r0);
+        launch_row_norms(d_x + r0 * x_rs, rows, x_rs, (int)cb->M, (int)cb->dsub, xx, st);
+        EncodeArgs a;
+        a.x = d_x + r0 * x_rs; a.n = rows; a.x_rs = x_rs; a.out = keys; a.o_rs = Mv;
+        a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
+        a.M = (int)Mv; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
+        a.groups = cb->groups;
+        a.bad_flag = nullptr;
+        // one wave per SIMD and one workgroup per CU: ~4 row streams per CU and round
+        int64_t rpi = round_up((rows * Mv + 4 * 1024 - 1) / (4 * 1024), 32);
+        rpi = std::max<int64_t>(32, std::min<int64_t>(512, rpi));
+        a.rows_per_item = (int)rpi;
+        a.n_chunks = (rows + 4 * rpi - 1) / (4 * rpi);
+        a.chunks_per_xcd = (a.n_chunks + 7) / 8;
+        const dim3 grid((unsigned)(a.chunks_per_xcd * Mv * 8));
+        if (!launch_encode_wide(cb->T, cb->DP, a, xx, grid, st)) return PQHIP_EUNSUPPORTED;
+        const unsigned mg = (unsigned)std::min<int64_t>((rows * cb->M + 255) / 256, 256 * 32);
+        if (code_bytes == 1)
+            hipLaunchKernelGGL((k_merge_keys<uint8_t>), dim3(mg), dim3(256), 0, st, (const unsigned long long*)keys, rows, (int)cb->M, cb->groups,
+                               (uint8_t*)d_codes + r0 * o_rs, o_rs);
+        else
+            hipLaunchKernelGGL((k_merge_keys<uint32_t>), dim3(mg), dim3(256), 0, st, (const unsigned long long*)keys, rows, (int)cb->M, cb->groups,
+                               (uint32_t*)d_codes + r0 * o_rs, o_rs);
+        HIPCHK(hipGetLastError());
+    }
+    cb->last_kernel = "k_encode_mfma_wide";
+    return PQHIP_OK;
+}
+
 // PQ encode of device-resident, already rotated rows.
 // bad_flag != nullptr: the matrix-core kernel is launched whatever the host last knew about the
 // centroid norms and consults the device flag itself (captured k-means iterations).
@@ -511,6 +557,11 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     if (n == 0) return PQHIP_OK;
     if ((cb->variant == 5 || cb->variant == 8) && !cb->has_proj) return PQHIP_EUNSUPPORTED;   // variants 5 / 8 = fused OPQ kernels only
     CodebookDev& cd = cb->dev[slot];
+    if (cb->wide) {
+        if (cb->variant != 1 && cb->norms_ok && (code_bytes == 1 || code_bytes == 4))
+            return encode_wide_dev(cb, slot, d_x, n, x_rs, d_codes, code_bytes, o_rs, st);
+        // (anything else: the scalar anchor kernel below)
+    } else
     if (cb->groups > 1 && cb->variant != 1 && cb->norms_ok && code_bytes == 4)
         return encode_grouped_dev(cb, slot, d_x, n, x_rs, d_codes, o_rs, st);
     // K <= 16 with sub-vectors of 2 / 4 / 8 / 16 floats: one matrix tile serves two subquantizers, x is read once in whole
@@ -568,7 +619,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     if (cb->variant == 6) return PQHIP_EUNSUPPORTED;
     // MFMA kernels: u8 codes from every variant, u32 codes (k-means assignments, wide index types)
     // from the default variant; K <= 256 here (larger K: encode_grouped_dev above, or the anchor)
-    const bool mfma_possible = cb->groups == 1 && cb->T != 0 && (cb->norms_ok || bad_flag != nullptr) &&
+    const bool mfma_possible = !cb->wide && cb->groups == 1 && cb->T != 0 && (cb->norms_ok || bad_flag != nullptr) &&
                                (code_bytes == 1 || (code_bytes == 4 && (cb->variant == 0 || cb->variant == 4 || cb->variant == 9)));
     bool use_mfma = mfma_possible;
     if (cb->variant == 1) use_mfma = false;
@@ -988,6 +1039,14 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
             groups = (int)((K + 255) / 256);
         }
     }
+    if (K <= 65536 && dsub > 128 && dsub <= 256) {
+        // one chain of up to 256 k is still a single rule-2 block; groups of <= 128 centroids keep the fragments within LDS
+        DP = (int)round_up(dsub, 16);
+        const int tiles = (int)((std::min<int64_t>(K, 128) + 31) / 32);
+        T = tiles <= 1 ? 1 : tiles <= 2 ? 2 : 4;
+        groups = (int)((K + 32 * T - 1) / (32 * T));
+        cb->wide = true;
+    }
     cb->T = T; cb->DP = DP; cb->groups = groups;
     cb->KP = (T != 0 && smallk_has((int)dsub)) ? smallk_kp(K) : 0;
     {   // pair kernel: K <= 16, power-of-two sub-vectors up to 16 floats, fragment image + slabs within 160 KB of LDS
@@ -1205,7 +1264,7 @@ int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n
     // finite-norm decision stays on the device inside the graph (bad_flag).  Any failure to capture
     // or instantiate falls back to the eager loop below, which has not run anything yet.
     int it0 = 0;
-    const bool try_graph = nwin == 1 && cb->groups == 1 && cb->T != 0 && cb->variant != 1 && n_iterations >= 3 &&
+    const bool try_graph = nwin == 1 && cb->groups == 1 && !cb->wide && cb->T != 0 && cb->variant != 1 && n_iterations >= 3 &&
                            n <= (1 << 20) && !getenv("PQHIP_DEBUG_KM_NOGRAPH");
     if (try_graph) {
         HIPCHK(hipEventRecord(aux.done, st));            // the instances and the codebook are ready on st

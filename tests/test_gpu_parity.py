@@ -106,7 +106,7 @@ SHAPES = [  # n, M, K, dsub
     (257, 3, 200, 32),      # largest resident fragment set
     (100, 4, 300, 6),       # K > 256 -> wider index type, anchor kernel
     (64, 2, 64, 40),        # wide sub-vectors
-    (50, 2, 40, 130),       # dsub > 128 -> anchor kernel
+    (50, 2, 40, 260),       # dsub > 256 -> anchor kernel
     (33, 1, 1, 5),          # K = 1
     (1, 15, 256, 20),       # single row
 ]
@@ -326,10 +326,12 @@ def test_more_than_256_centroids_on_the_matrix_path(ra, shape):
     assert gq.tobytes() == wq.tobytes() and gl.tobytes() == wl.tobytes()
 
 
-@pytest.mark.parametrize("dsub", [33, 36, 40, 41, 47, 48, 50, 56, 57, 60, 63, 64, 65, 72, 80, 81, 96, 100, 112, 127, 128])
+@pytest.mark.parametrize("dsub", [33, 36, 40, 41, 47, 48, 50, 56, 57, 60, 63, 64, 65, 72, 80, 81, 96, 100, 112, 127, 128,
+                                  129, 144, 150, 176, 192, 200, 255, 256])
 def test_wide_subvectors_on_the_matrix_path(ra, dsub):
     """32 < dsub <= 128: the default kernel with one wave per SIMD and 20..64-MFMA chains (DP = 40,
-    48, 56, 64, 80, 96, 112, 128 with zero k-padding) -- codes equal the oracle's, K <= 256 and grouped K > 256,
+    48, 56, 64, 80, 96, 112, 128 with zero k-padding); 128 < dsub <= 256: k_encode_mfma_wide (groups of <= 128 centroids,
+    norms by a pre-pass, keys merged) -- codes equal the oracle's, K <= 256 and grouped K > 256,
     special values included; the k-means step on top of it."""
     for (n, M, K) in [(777, 3, 256), (300, 2, 37), (500, 2, 300)]:
         q = synth.normalish(1400 + dsub + K, (M, K, dsub))
@@ -341,7 +343,7 @@ def test_wide_subvectors_on_the_matrix_path(ra, dsub):
         want = orc.quantize_batch(q, x, dtype=dt)
         pq = _pq(ra, q)
         assert pq.quantize_batch(x, dtype=dt).tobytes() == want.tobytes(), (n, M, K)
-        assert pq.last_encode_kernel().startswith(("k_encode_mfma_lds3", "k_encode_mfma16"))
+        assert pq.last_encode_kernel().startswith(("k_encode_mfma_lds3", "k_encode_mfma16") if dsub <= 128 else "k_encode_mfma_wide")
         rec = pq.reconstruct_batch(want)
         assert rec.tobytes() == orc.reconstruct_batch(q, want).tobytes()
     q0, xs = _km_inputs(1200, 2, 16, dsub, 1500 + dsub)
