@@ -7,10 +7,11 @@
 // 256 centroids: DP KB).  So this kernel is deliberately plain:
 //   * a codebook is presented in GROUPS of 32 T <= 128 centroids (the grouped machinery of K > 256: one 64-bit key
 //     {ordered distance, global index} per (row, group), k_merge_keys takes the minimum), T <= 4 tiles = 128 KB of fragments;
-//   * no software pipeline: a wave loads its 32-row tile (lane (row j, half h) fetches one half of the sub-vector, one
-//     v_permlane32_swap per register pair makes the B operands, as in the default kernel), waits, runs T chains with the
-//     fragments read from LDS as they are needed, and keeps the running minimum key in registers -- a chain is 5,000-8,000
-//     cycles long, the 48 vector instructions of a lane-local argmin and the exposed load are a few per cent of it;
+//   * one prefetch instead of a software pipeline: a wave's 32-row tile (lane (row j, half h) fetches one half of the
+//     sub-vector, one v_permlane32_swap per register pair makes the B operands, as in the default kernel) is requested one
+//     tile ahead; the wave then runs T chains with the fragments read from LDS as they are needed and keeps the running
+//     minimum key in registers -- a chain is 5,000-8,000 cycles long, the 48 vector instructions of a lane-local argmin are
+//     a few per cent of it;
 //   * ||x||^2 comes from a pre-pass (k_row_norms: rule 1 needs the elements of a sub-vector in ndarray's order, which the
 //     split operand layout does not keep for a run-time length), 4 M bytes per row.
 // Exact path and key format as in k_encode_mfma_lds3 (KEYS mode): a negative or non-finite minimum or a huge norm sends the
@@ -74,28 +75,49 @@ __global__ __launch_bounds__(256, 1) void k_encode_mfma_wide(EncodeArgs a, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) lo[r] = (r & 3) + 8 * (r >> 2) + 4 * h;       // centroid of accumulator register r inside a tile
 
+    // the raw half-rows of the NEXT tile travel from HBM while this tile's chains run (the only overlap this kernel has)
+    float v[DP / 2];
+    float xr_next;
+    {
+        const int64_t row = (row_begin + j < a.n) ? row_begin + j : a.n - 1;    // rows past the end: clamped, never stored
+        load_row_floats_rt<DP / 2>(xcol + row * a.x_rs, cnt, v);
+        xr_next = xx[row * Mreal + m_real];
+    }
     for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
-        const int64_t row = (row0 + j < a.n) ? row0 + j : a.n - 1;              // rows past the end: clamped, never stored
         float bop[S];
-        {
-            float v[DP / 2];
-            load_row_floats_rt<DP / 2>(xcol + row * a.x_rs, cnt, v);
 #pragma unroll
-            for (int i = 0; i < DP / 4; ++i) {
-                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * i]), __float_as_uint(v[2 * i + 1]), false, false);
-                bop[i] = __uint_as_float(r[0]);             // half 0: x[2i],        half 1: x[2i + 1]
-                bop[DP / 4 + i] = __uint_as_float(r[1]);    // half 0: x[DP/2 + 2i], half 1: x[DP/2 + 2i + 1]
-            }
+        for (int i = 0; i < DP / 4; ++i) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * i]), __float_as_uint(v[2 * i + 1]), false, false);
+            bop[i] = __uint_as_float(r[0]);             // half 0: x[2i],        half 1: x[2i + 1]
+            bop[DP / 4 + i] = __uint_as_float(r[1]);    // half 0: x[DP/2 + 2i], half 1: x[DP/2 + 2i + 1]
         }
-        const float xr = xx[row * Mreal + m_real];
+        const float xr = xr_next;
+        {
+            const int64_t nr0 = (row0 + 32 < row_end) ? row0 + 32 : row0;        // (last tile: its own rows again, unused)
+            const int64_t row = (nr0 + j < a.n) ? nr0 + j : a.n - 1;
+            load_row_floats_rt<DP / 2>(xcol + row * a.x_rs, cnt, v);
+            xr_next = xx[row * Mreal + m_real];
+        }
         const f32x2 xx2 = {xr, xr};
         long long best = 0x7fffffffffffffffll;
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
             f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const float* af = afrag_s + (t * S) * 64 + lane;
+            // one wave per SIMD and one dependent chain: nothing hides an LDS round trip but the chain itself, so the
+            // fragments are requested PF matrix instructions (PF x 64 cycles) ahead of their use
+            constexpr int PF = 8;
+            float fr[PF];
 #pragma unroll
-            for (int s = 0; s < S; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s * 64], bop[s], acc, 0, 0, 0);
+            for (int i = 0; i < PF; ++i) fr[i] = af[i * 64];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float fa = fr[s % PF];
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + PF < S) fr[s % PF] = af[(s + PF) * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, bop[s], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 c4 = *reinterpret_cast<const f32x4*>(&cc_s[32 * t + 8 * g + 4 * h]);
