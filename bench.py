@@ -79,6 +79,49 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU cores this process may actually use: the cgroup CPU quota (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us`)
+    and the scheduler affinity, whichever is smaller -- NOT os.cpu_count(), which reports the host's logical CPUs
+    (256 on the GPU boxes, of which a one-GPU job is granted 16: `cpu.max = 1600000 100000`)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
+def per_step(log, steps):
+    """'k_a x20 + k_b x60' over 20 timed steps -> 'k_a + k_b x3' (counts that are not whole multiples stay as logged)."""
+    out = []
+    for part in [p for p in log.split(" + ") if p]:
+        name, _, cnt = part.rpartition(" x")
+        if not name or not cnt.isdigit():
+            name, cnt = part, "1"
+        c = int(cnt)
+        if steps > 0 and c % steps == 0:
+            c //= steps
+            out.append(name if c == 1 else "%s x%d" % (name, c))
+        else:
+            out.append("%s x%d/%d steps" % (name, c, steps))
+    return " + ".join(out)
+
+
 def shard_ranges(world, rows):
     """weak scaling: rank r owns global rows [r*rows, (r+1)*rows)."""
     return [[r * rows, (r + 1) * rows] for r in range(world)]
@@ -137,6 +180,7 @@ class Bench:
         torch.cuda.synchronize()
         self.barrier()
         torch.cuda.synchronize()
+        self.ra.launch_log(reset=True)               # from here on: the launches of the K timed steps only
         t0 = time.perf_counter()
         for a, b in evs:
             a.record()                            # torch's current stream = the stream passed to the C ABI
@@ -177,7 +221,6 @@ class Bench:
             src = torch.randint(0, k, (rows, m), device=self.dev, dtype=torch.uint8, generator=g)
             dst = torch.empty((rows, d), device=self.dev, dtype=torch.float32)
             step = lambda: pq.reconstruct_batch_device(src, out=dst, check=False)
-            kernel = "k_reconstruct" if workload == "reconstruct" else "k_reconstruct + k_rotate_pblock6 (x P^T)"
         elif workload == "lookup":
             n_codes = args.lookup_codes
             src = torch.randint(0, k, (n_codes, m), device=self.dev, dtype=torch.uint8, generator=g)
@@ -190,7 +233,6 @@ class Bench:
                 rec, rec_off = self.ra.Pq.interleave_records(src, scl, record_bytes=args.record_bytes)
                 step = lambda: pq.reconstruct_records_device(rec, rec_off, sel, out=dst, check=False)
                 extra["layout"] = "interleaved %d-byte records (codes at 0, f32 scale at %d)" % (rec.shape[1], rec_off)
-            kernel = "k_reconstruct<.., SEL>"
         elif workload == "adc_scan":
             src = torch.randint(0, k, (rows, m), device=self.dev, dtype=torch.uint8 if k <= 256 else torch.int32, generator=g)
             nq = max(1, args.queries)
@@ -199,7 +241,6 @@ class Bench:
             lut = pq.adc_tables_device(query)
             extra["queries_per_scan"] = nq
             step = lambda: pq.adc_scan_device(src, lut, out=dst)
-            kernel = "k_adc_scan"
         else:
             src = self.normal_rows(rows, d, 42 + self.rank)
             dst = torch.empty((rows, m), device=self.dev, dtype=torch.uint8 if k <= 256 else torch.int32)
@@ -228,6 +269,7 @@ class Bench:
             torch.cuda.synchronize()
             self.barrier()
             torch.cuda.synchronize()
+            self.ra.launch_log(reset=True)
             t0 = time.perf_counter()
             run_steps(steps)
             torch.cuda.synchronize()
@@ -237,10 +279,12 @@ class Bench:
             kernel_ms = kmin = kmax = 1e3 * elapsed / steps
         else:
             elapsed, kernel_ms, kmin, kmax = self.timed(step, steps, warmup)
-        if kernel is None:
-            kernel = pq.last_encode_kernel() if workload != "kmeans" else None
-        if kernel:
-            extra["encode_kernel" if workload not in ("reconstruct", "opq_reconstruct", "lookup", "adc_scan") else "kernel"] = kernel
+        # what the timed steps actually launched (the library's launch log of this thread: distinct kernel names with
+        # counts over the K timed steps) -- never a string table
+        kernel = per_step(self.ra.launch_log(reset=True), steps)
+        extra["kernels_launched_per_step"] = kernel
+        if workload in ("encode", "encode_d768", "opq_encode", "opq_train"):
+            extra["encode_kernel"] = pq.last_encode_kernel()
 
         sec = kernel_ms * 1e-3
         traffic_rec, why = load_pmc_traffic(workload, rows, d, m, k, "_q%d" % args.queries if (workload == "adc_scan" and args.queries > 1) else "")
@@ -262,12 +306,9 @@ class Bench:
             if workload == "opq_reconstruct":     # the inverse rotation only (+ 2 d^2 per vector)
                 flop = 2 * d * d
             ach = flop * rows / sec / 1e12
-            ek = kernel or "k_encode_mfma_lds3"
             roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                    "kernel": {"encode": ek, "encode_d768": ek, "opq_reconstruct": ek, "opq_encode": ("k_opq_encode_fused (rotation + encode in one kernel)" if ek == "k_opq_encode_fused" else "k_rotate_pblock6 + " + ek),
-                               "kmeans": "encode kernel + k_km_{hist,scan,scatter,segsum} + codebook prep (whole iteration)",
-                               "opq_train": "k_rotate_pblock6 + 2 x " + ek + " + k_km_* + k_reconstruct + k_atb_blocks/fold (whole step)"}[workload],
+                    "kernel": kernel,
                     "avg_launch_ms": kernel_ms, "min_launch_ms": kmin, "max_launch_ms": kmax,
                     "algorithmic_flop_per_vector": flop, "algorithmic_bytes_per_vector": bytes_vec,
                     "hbm_gbs": bytes_vec * rows / sec / 1e9, "hbm_frac": bytes_vec * rows / sec / 1e9 / PEAK_HBM_GBS}
@@ -482,8 +523,8 @@ def in_process(args, d, m, k, rows):
         n_s = min(rows, 200_000)
         tail = slice(rows - n_s, rows)
         rec["codes_identical_to_oracle_head_and_tail"] = bool(
-            (orc.quantize_batch(q, x[:n_s], n_threads=os.cpu_count() or 1) == out[:n_s]).all()
-            and (orc.quantize_batch(q, x[tail], n_threads=os.cpu_count() or 1) == out[tail]).all())
+            (orc.quantize_batch(q, x[:n_s], n_threads=host_cores()) == out[:n_s]).all()
+            and (orc.quantize_batch(q, x[tail], n_threads=host_cores()) == out[tail]).all())
     return rec
 
 
@@ -493,7 +534,7 @@ def cpu_baseline(args, q, P, src, dst, pq, full=True):
     The oracle is used here only as the thing timed/checked -- never as the product."""
     from oracle import pq_oracle as orc
     import numpy as np
-    cores = os.cpu_count() or 1
+    cores = host_cores()                          # the CPU quota of this job = the threads the oracle is given
     d = src.shape[1]
     scale = max(1, (d * (2 if P is not None else 1)) // 300)      # keep the sample's CPU work bounded for wide / OPQ shapes
     n_mt = min(args.cpu_rows // scale, src.shape[0])
@@ -511,7 +552,7 @@ def cpu_baseline(args, q, P, src, dst, pq, full=True):
     xt = src[-n_tail:].cpu().numpy()
     same_tail = bool((dst[-n_tail:].cpu().numpy().astype(np.int64) ==
                       orc.quantize_batch(q, xt, projection=P, n_threads=cores, dtype=np.uint32).astype(np.int64)).all())
-    rec = {"value": n_mt / t_mt, "unit": "vectors/s", "cores": cores, "kind": "port",
+    rec = {"value": n_mt / t_mt, "unit": "vectors/s", "cores": cores, "logical_cpus": os.cpu_count(), "kind": "port",
            "sample": "first %d rows of the bench batch, oracle sharded over %d threads (%.1f s); "
                      "single-thread: %d rows; parity also on the last %d rows" % (n_mt, cores, t_mt, n_st, n_tail),
            "single_thread_value": n_st / t_st, "simd": "avx2+fma" if orc.lib().pqo_uses_fma_simd() else "scalar",
@@ -591,14 +632,14 @@ def cpu_baseline_kmeans(args, q0, src, ctx):
     checked bit for bit (centroids and losses)."""
     from oracle import pq_oracle as orc
     from reductive_amd.pq import kmeans_iterations
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     n_s = min(args.cpu_rows // 2, src.shape[0])
     x = src[:n_s].cpu().numpy()
     t = time.perf_counter()
     want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=1, n_threads=cores)
     t_cpu = time.perf_counter() - t
     got_q, got_loss = kmeans_iterations(q0, src[:n_s], n_iterations=1, want_loss=True, ctx=ctx)
-    return {"value": n_s / t_cpu, "unit": "vectors/s", "cores": cores, "kind": "port",
+    return {"value": n_s / t_cpu, "unit": "vectors/s", "cores": cores, "logical_cpus": os.cpu_count(), "kind": "port",
             "sample": "one iteration over the first %d rows of the bench batch; oracle assignment on %d "
                       "threads, update + loss sequential (%.1f s)" % (n_s, cores, t_cpu),
             "gpu_centroids_identical_on_sample": bool(got_q.tobytes() == want_q.tobytes()),

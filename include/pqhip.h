@@ -134,8 +134,8 @@ int32_t pqhip_reconstruct_rows_f32_dev(pqhip_codebook *cb, int32_t device_slot, 
  * holding the M codes of a row at offset 0 and its f32 scale at `scale_offset_bytes` (both multiples of 4 bytes;
  * `record_bytes` also a multiple of `code_bytes`).  With 32-byte records at M = 15 (15 code bytes, 1 pad, the scale
  * at offset 16, 12 pad) a lookup touches ONE 128-byte line where the split layout above touches one for the 15-byte
- * code row (12 % of which straddle two) and one for the scale -- the resident-matrix layout of
- * reductive_amd.qmatrix.QuantizedMatrix(interleave=True).  Semantics and results are those of
+ * code row (12 % of which straddle two) and one for the scale -- the layout `reductive_amd.Pq.interleave_records`
+ * builds and `Pq.reconstruct_records_device` consumes.  Semantics and results are those of
  * pqhip_reconstruct_rows_f32_dev with d_scales given.
  */
 int32_t pqhip_reconstruct_rows_records_f32_dev(pqhip_codebook *cb, int32_t device_slot, const void *d_records,
@@ -260,25 +260,42 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float 
                                int64_t b_row_stride, int64_t db, int64_t n_rows, float *out,
                                void *stream);
 
-/* ---- knobs used by the test-suite and the bench (not part of the reference surface) -------- */
-/* force a kernel variant for encode: 0 = auto, 1 = scalar VALU anchor kernel,
- * 2 = MFMA kernel with VALU argmin, 3 = MFMA + LDS-atomic argmin with register-resident codebook
- * fragments (2 waves/SIMD), 4 = MFMA + LDS-atomic argmin with LDS-resident fragments (3 waves/SIMD;
- * the auto choice wherever variant 9 has no instantiation), 5 = OPQ codebooks only: rotation and encode fused in one kernel, no scratch buffer
- * (PQHIP_EUNSUPPORTED for shapes it has no instantiation for), 6 = the VALU kernel for small codebooks
- * (K <= 64, u8 codes; the auto choice for K <= 16 with sub-vectors of 6 or 8 floats, and of 4 floats below 48
- * subquantizers), 7 = K <= 16, sub-vectors of 2 / 4 / 8 / 16 floats: the kernel that serves two subquantizers per
- * matrix tile (the auto choice for 2 floats, and for 4 floats from 48 subquantizers on), 8 = OPQ codebooks only: the
- * second-generation fused kernel (P block and codebook fragments in LDS; the auto choice for the shapes it is instantiated
- * for, PQHIP_EUNSUPPORTED otherwise), 9 = the LDS-atomic argmin on the 16x16x4 matrix instruction, four waves per
- * SIMD (>= 64 centroids and sub-vectors of 4, 8, .., 32 floats, PQHIP_EUNSUPPORTED otherwise; the auto choice for more than
- * 128 centroids and 12 .. 24 floats) */
+/* ---- knobs used by the test-suite and the bench (not part of the reference surface) --------
+ * The library reads three environment variables (PQHIP_PACK_THREADS, PQHIP_HOST_ZERO_COPY, PQHIP_FUSED2_OPQ: all
+ * about the host path / deployment); every other switch is an explicit call below.
+ *
+ * pqhip_set_encode_variant: force an encode kernel family on one codebook (PQHIP_EUNSUPPORTED from the next
+ * quantize call when the family has no instantiation for the shape):
+ *   0  auto
+ *   1  scalar anchor kernel (exact by construction, any shape)
+ *   2  MFMA 32x32x2 with a lane-local (VALU) argmin          auto for sub-vectors of <= 2 floats
+ *   4  MFMA 32x32x2, LDS-atomic argmin, fragments in LDS     auto wherever 9 is not taken; K > 256; k-means
+ *   6  VALU kernel for small codebooks (K <= 64, u8 codes)   auto for K <= 16 with sub-vectors of <= 8 floats
+ *   7  two subquantizers per matrix tile (K <= 16)           auto for 2 floats, and 4 floats from 48 subquantizers on
+ *   8  OPQ only: rotation + encode in one kernel             auto where instantiated (opq_fused2_launch.h)
+ *   9  MFMA 16x16x4, LDS-atomic argmin, four waves per SIMD  auto for K > 128 and sub-vectors of 12 .. 24 floats
+ *   (3 and 5 named kernels that rounds 1-2 shipped; PQHIP_EINVAL since round 4)                                  */
 int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);
-/* process-wide: the OPQ rotation kernel where both exist (P block within LDS, 16-byte aligned rows): 0 = auto (the
- * 16x16x4 form, k_rotate_pblock9, when the rows are gathered from the codebook inside the kernel -- OPQ reconstruct --
- * and for plain rotation where the 64-column blocks of the 32x32x2 form, k_rotate_pblock8, would execute >= 10 % more
- * columns than 16-column tiles, e.g. d = 96, 144, 272, 400; k_rotate_pblock8 otherwise), 8 / 9 force one of them     */
+/* process-wide: the P-block rotation kernel where both exist (16-byte aligned rows, d % 4 == 0):
+ *   0  auto: k_rotate_pblock9 (16x16x4) for the gather form (OPQ reconstruct), for d > 640, and for plain rotation
+ *      where 64-column blocks would execute >= 10 % more columns than 16-column tiles (d = 96, 144, 272, 400 ..);
+ *      k_rotate_pblock8 (32x32x2) otherwise
+ *   8 / 9  force one of them                                                                                    */
 int32_t pqhip_set_rotation_variant(int32_t variant);
+/* per-context options (value >= 0; PQHIP_EINVAL for an unknown name):
+ *   "kmeans_window_rows"   rows per window of the k-means iteration (0 = default, 512 K)
+ *   "kmeans_lane_form"     1 = lane-per-chain update walk for every shape
+ *   "kmeans_no_graph"      1 = never replay small training sets as a captured hipGraph
+ *   "opq_scratch_rows"     rows per chunk of the two-kernel OPQ paths (0 = whole rounds of the rotation grid)
+ *   "opq_fused"            0 = OPQ encode as rotation -> scratch -> encode (default 1; PQHIP_FUSED2_OPQ=0 presets 0)
+ *   "opq_gather_rotation"  0 = OPQ reconstruct as gather -> scratch -> rotation (default 1)
+ *   "adc_single_query"     1 = one scan pass per query (default 0: 8 / 4 queries share a pass)                  */
+int32_t pqhip_ctx_set_option(pqhip_ctx *ctx, const char *name, int64_t value);
+/* Launch log of the calling thread: every kernel the library launches is noted by name; pqhip_launch_log() renders
+ * "k_a + k_b x3 + ..." (distinct names in first-launch order with counts; valid until the thread's next call of
+ * it), pqhip_launch_log_reset() clears it.  bench.py reports roofline.kernel from it.                            */
+const char *pqhip_launch_log(void);
+void pqhip_launch_log_reset(void);
 /* name of the encode kernel the last device call on this codebook launched ("" if none)        */
 const char *pqhip_last_encode_kernel(const pqhip_codebook *cb);
 

@@ -12,14 +12,16 @@
 //   * `get()` returns a PIN (shared ownership of the entry, Rust: `Arc<Entry>`): an entry evicted or replaced
 //     while calls are running on it is destroyed when its last pin is dropped, so eviction waits for users and
 //     users never wait for each other;
-//   * a hit is validated by (data pointers, lengths, shape), a SAMPLED 64-bit content hash -- the first and last
-//     4 KiB of quantizers and projection plus 256 evenly spaced 8-byte words of each: a few microseconds, where
-//     hashing all of a d = 768 OPQ quantizer (3.1 MB) cost about as much as a 4,096-row encode -- and a
-//     GENERATION counter that the training entry points bump (`invalidate()`): centroids updated in place by
-//     `try_kmeans_iterations` / `train_step` can never be served from a stale image.  A dropped `Pq` whose
-//     allocation is reused by another quantizer, or centroids rewritten by the CPU trainer (every centroid moves),
-//     change the sample; an edit confined to bytes outside the sample AND outside the binding is the one case the
-//     sample misses (the reference has no such code path: `Pq` exposes no `&mut` access to its arrays);
+//   * a hit is validated by (data pointers, lengths, shape), the FULL 64-bit content hash of quantizers and
+//     projection, and a GENERATION counter that every training exit bumps (`invalidate()`).  Round 3 validated a
+//     sample of the arrays (head, tail, 256 spread words) to save ~70 us per call; a `Pq` dropped and another one
+//     allocated at the same address that differs only outside the sample (one fine-tuned centroid) was then
+//     served the OLD device image -- silently wrong codes.  Correctness is not
+//     what gets traded: the hash is complete again, and the cost went into the hash instead -- eight independent
+//     lanes, one AES round per 16 bytes where the host has AES-NI (multiply-xorshift lanes otherwise), run at the
+//     speed of the cache the arrays sit in (measured on the GPU boxes: tests/cpp/test_codebook_cache.cpp prints it),
+//     where the word-serial FNV chain of round 2 ran at ~5 GB/s.  Every lane update is a bijection of the lane
+//     state, so ANY single changed word changes the hash unless the final 64-bit fold collides (2^-64);
 //   * at most `capacity` entries, least recently used evicted -- no unbounded device memory.
 // The handle type and its create / destroy functions are template parameters: the product instantiates it
 // with pqhip_codebook*, the CPU unit test with counters.
@@ -33,37 +35,85 @@
 
 namespace reductive_amd {
 
-// FNV-1a over 8-byte words (tail bytes folded in): a checksum for change detection, not a cryptographic hash.
-inline uint64_t content_hash(const void* data, size_t bytes, uint64_t h = 0xcbf29ce484222325ull)
+// Full-content checksum for change detection (not a cryptographic hash): EVERY byte is read.
+// Portable form: blocks of 64 bytes feed eight independent 64-bit lanes (lane j sees word j of every block),
+// h_j = xorshift((h_j ^ w) * prime) -- a bijection of the lane state per step, so a single changed word always
+// changes its lane; the eight multiply chains overlap, the loop runs at one 64-bit multiply per cycle (8 B/cycle).
+inline uint64_t content_hash_lanes(const void* data, size_t bytes, uint64_t h)
 {
+    constexpr uint64_t kPrime = 0x100000001b3ull;
     const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint64_t l[8];
+    for (int j = 0; j < 8; ++j) l[j] = h ^ (0x9e3779b97f4a7c15ull * (uint64_t)(j + 1));
     size_t i = 0;
+    for (; i + 64 <= bytes; i += 64) {
+        uint64_t w[8];
+        __builtin_memcpy(w, p + i, 64);
+        for (int j = 0; j < 8; ++j) {
+            l[j] = (l[j] ^ w[j]) * kPrime;
+            l[j] ^= l[j] >> 29;
+        }
+    }
+    h ^= (uint64_t)bytes * kPrime;
+    for (int j = 0; j < 8; ++j) {
+        h = (h ^ l[j]) * kPrime;
+        h ^= h >> 29;
+    }
     for (; i + 8 <= bytes; i += 8) {
         uint64_t w;
         __builtin_memcpy(&w, p + i, 8);
-        h = (h ^ w) * 0x100000001b3ull;
+        h = (h ^ w) * kPrime;
         h ^= h >> 29;
     }
-    for (; i < bytes; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+    for (; i < bytes; ++i) h = (h ^ p[i]) * kPrime;
     return h;
 }
 
-// The sampled form: everything when the array is small, else head + tail + 256 words spread over the middle.
-inline uint64_t sampled_hash(const void* data, size_t bytes, uint64_t h = 0xcbf29ce484222325ull)
+#if defined(__x86_64__)
+// x86 hosts with AES-NI (every EPYC / Xeon a GPU node is built from): eight 128-bit lanes, one AES round per
+// 16 bytes -- state' = AESENC(state ^ block, key) is a permutation of the state for every block and of the block
+// for every state, so the single-changed-word argument holds here too -- at 16-32 B/cycle: the hash of a codebook
+// runs at the speed of the cache level it sits in.
+typedef long long pqhip_v2di __attribute__((vector_size(16), aligned(16)));
+typedef long long pqhip_v2di_u __attribute__((vector_size(16), aligned(1)));
+__attribute__((target("aes,sse2"))) inline uint64_t content_hash_aes(const void* data, size_t bytes, uint64_t h)
 {
-    constexpr size_t kEdge = 4096, kWords = 256;
-    if (bytes <= 2 * kEdge + 8 * kWords) return content_hash(data, bytes, h);
     const unsigned char* p = static_cast<const unsigned char*>(data);
-    h = content_hash(p, kEdge, h);
-    h = content_hash(p + bytes - kEdge, kEdge, h);
-    const size_t span = bytes - 2 * kEdge, step = (span / kWords) & ~(size_t)7;
-    for (size_t i = 0; i < kWords; ++i) {
-        uint64_t w;
-        __builtin_memcpy(&w, p + kEdge + i * step, 8);
-        h = (h ^ w) * 0x100000001b3ull;
-        h ^= h >> 29;
+    const pqhip_v2di key = {(long long)0x9e3779b97f4a7c15ull, (long long)0xc2b2ae3d27d4eb4full};
+    pqhip_v2di s[8];
+    for (int j = 0; j < 8; ++j) s[j] = pqhip_v2di{(long long)(h + (uint64_t)j), (long long)(~h ^ ((uint64_t)j << 32))};
+    size_t i = 0;
+    for (; i + 128 <= bytes; i += 128)
+        for (int j = 0; j < 8; ++j) {
+            const pqhip_v2di b = *reinterpret_cast<const pqhip_v2di_u*>(p + i + 16 * j);
+            s[j] = __builtin_ia32_aesenc128(s[j] ^ b, key);
+        }
+    pqhip_v2di acc = {(long long)bytes, (long long)h};
+    for (int j = 0; j < 8; ++j) acc = __builtin_ia32_aesenc128(acc ^ s[j], key);
+    for (; i + 16 <= bytes; i += 16) {
+        const pqhip_v2di b = *reinterpret_cast<const pqhip_v2di_u*>(p + i);
+        acc = __builtin_ia32_aesenc128(acc ^ b, key);
     }
-    return h;
+    if (i < bytes) {
+        unsigned char tail[16] = {};
+        __builtin_memcpy(tail, p + i, bytes - i);
+        pqhip_v2di b;
+        __builtin_memcpy(&b, tail, 16);
+        acc = __builtin_ia32_aesenc128(acc ^ b, key);
+    }
+    acc = __builtin_ia32_aesenc128(acc, key);
+    acc = __builtin_ia32_aesenc128(acc, key);
+    return (uint64_t)acc[0] ^ (uint64_t)acc[1];
+}
+#endif
+
+inline uint64_t content_hash(const void* data, size_t bytes, uint64_t h = 0xcbf29ce484222325ull)
+{
+#if defined(__x86_64__)
+    static const bool has_aes = __builtin_cpu_supports("aes");
+    if (has_aes) return content_hash_aes(data, bytes, h);
+#endif
+    return content_hash_lanes(data, bytes, h);
 }
 
 template <typename Handle>
@@ -103,15 +153,15 @@ public:
     {
         const size_t q_len = (size_t)(M * K * dsub), d = (size_t)(M * dsub);
         const Key key{q, q_len, p, M, K, dsub};
-        uint64_t h = sampled_hash(q, q_len * sizeof(float));             // (outside the mutex: reads caller memory only)
-        if (p) h = sampled_hash(p, d * d * sizeof(float), h);
+        uint64_t h = content_hash(q, q_len * sizeof(float));             // FULL contents (outside the mutex: reads caller memory only)
+        if (p) h = content_hash(p, d * d * sizeof(float), h);
         const uint64_t gen = generation_.load(std::memory_order_acquire);
         Pin stale;                                                       // destroyed after the mutex is released
         {
             std::lock_guard<std::mutex> g(mu_);
             for (auto it = entries_.begin(); it != entries_.end(); ++it) {
                 if (!(it->key == key)) continue;
-                if (it->hash == h && it->gen == gen) {                   // same memory, same sample, nothing trained since
+                if (it->hash == h && it->gen == gen) {                   // same memory, same contents, nothing trained since
                     entries_.splice(entries_.begin(), entries_, it);
                     ++hits_;
                     return entries_.front().slot;

@@ -120,6 +120,12 @@ def lib():
     L.pqhip_set_rotation_variant.argtypes = [i32]
     L.pqhip_last_encode_kernel.restype = ctypes.c_char_p
     L.pqhip_last_encode_kernel.argtypes = [vp]
+    L.pqhip_ctx_set_option.restype = i32
+    L.pqhip_ctx_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+    L.pqhip_launch_log.restype = ctypes.c_char_p
+    L.pqhip_launch_log.argtypes = []
+    L.pqhip_launch_log_reset.restype = None
+    L.pqhip_launch_log_reset.argtypes = []
     L.pqhip_selftest_mfma_chain.restype = i32
     L.pqhip_selftest_mfma_chain.argtypes = [vp, i32, i32, i32, ctypes.c_uint64,
                                             ctypes.POINTER(i64)]
@@ -140,4 +146,5 @@ EXPORTS = [
     "pqhip_opq_train_step_f32_dev", "pqhip_at_dot_b_f32_dev", "pqhip_rotate_f32_dev",
     "pqhip_matrix_upload_f32", "pqhip_matrix_device_ptr", "pqhip_matrix_rows", "pqhip_matrix_destroy",
     "pqhip_set_encode_variant", "pqhip_set_rotation_variant", "pqhip_last_encode_kernel", "pqhip_selftest_mfma_chain",
+    "pqhip_ctx_set_option", "pqhip_launch_log", "pqhip_launch_log_reset",
 ]

@@ -5,7 +5,6 @@
 // PQ_DPSET 0: padded sub-dimension DP = 0 (mod 4), 1: DP = 2 (mod 4), 2: wide sub-vectors DP in
 // {40, 48, 56, 64, 80, 96, 112, 128} (default kernel only).
 #include "encode_launch.h"
-#include <cstdlib>
 #include "kernels_mfma_lds.hip.h"
 #include "kernels_mfma16.hip.h"
 
@@ -15,17 +14,9 @@
 
 namespace pqhip {
 
-// PQHIP_DEBUG_LDS_PAD=<bytes>: extra dynamic LDS per workgroup (occupancy experiments only)
-static unsigned debug_lds_pad()
-{
-    static const unsigned v = [] { const char* e = getenv("PQHIP_DEBUG_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
-    return v;
-}
-
 template <int KIND, int T, int DP>
-static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st)
+static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st, unsigned pad)
 {
-    const unsigned pad = debug_lds_pad();
     if constexpr (KIND == 3) {
         if constexpr (T >= 2 && DP % 4 == 0 && DP <= 32) {
             if (!vec || a.rows_per_item > 32 * kMfma16MaxTiles) return false;
@@ -68,31 +59,31 @@ static bool launch_vec(bool vec, int code_bytes, const EncodeArgs& a, dim3 grid,
 }
 
 template <int KIND, int T, int DPSET>
-bool launch_encode_mfma_t(int DP, bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st)
+bool launch_encode_mfma_t(int DP, bool vec, int code_bytes, const EncodeArgs& a, dim3 grid, hipStream_t st, unsigned pad)
 {
     if constexpr (DPSET == 0) {
         switch (DP) {
-        case 4: return launch_vec<KIND, T, 4>(vec, code_bytes, a, grid, st);
-        case 8: return launch_vec<KIND, T, 8>(vec, code_bytes, a, grid, st);
-        case 12: return launch_vec<KIND, T, 12>(vec, code_bytes, a, grid, st);
-        case 16: return launch_vec<KIND, T, 16>(vec, code_bytes, a, grid, st);
-        case 20: return launch_vec<KIND, T, 20>(vec, code_bytes, a, grid, st);
-        case 24: return launch_vec<KIND, T, 24>(vec, code_bytes, a, grid, st);
-        case 28: return launch_vec<KIND, T, 28>(vec, code_bytes, a, grid, st);
-        case 32: return launch_vec<KIND, T, 32>(vec, code_bytes, a, grid, st);
+        case 4: return launch_vec<KIND, T, 4>(vec, code_bytes, a, grid, st, pad);
+        case 8: return launch_vec<KIND, T, 8>(vec, code_bytes, a, grid, st, pad);
+        case 12: return launch_vec<KIND, T, 12>(vec, code_bytes, a, grid, st, pad);
+        case 16: return launch_vec<KIND, T, 16>(vec, code_bytes, a, grid, st, pad);
+        case 20: return launch_vec<KIND, T, 20>(vec, code_bytes, a, grid, st, pad);
+        case 24: return launch_vec<KIND, T, 24>(vec, code_bytes, a, grid, st, pad);
+        case 28: return launch_vec<KIND, T, 28>(vec, code_bytes, a, grid, st, pad);
+        case 32: return launch_vec<KIND, T, 32>(vec, code_bytes, a, grid, st, pad);
         default: return false;
         }
     } else if constexpr (DPSET == 2) {
         if constexpr (KIND == 2) {
             switch (DP) {
-            case 40: return launch_vec<KIND, T, 40>(vec, code_bytes, a, grid, st);
-            case 48: return launch_vec<KIND, T, 48>(vec, code_bytes, a, grid, st);
-            case 56: return launch_vec<KIND, T, 56>(vec, code_bytes, a, grid, st);
-            case 64: return launch_vec<KIND, T, 64>(vec, code_bytes, a, grid, st);
-            case 80: return launch_vec<KIND, T, 80>(vec, code_bytes, a, grid, st);
-            case 96: return launch_vec<KIND, T, 96>(vec, code_bytes, a, grid, st);
-            case 112: return launch_vec<KIND, T, 112>(vec, code_bytes, a, grid, st);
-            case 128: return launch_vec<KIND, T, 128>(vec, code_bytes, a, grid, st);
+            case 40: return launch_vec<KIND, T, 40>(vec, code_bytes, a, grid, st, pad);
+            case 48: return launch_vec<KIND, T, 48>(vec, code_bytes, a, grid, st, pad);
+            case 56: return launch_vec<KIND, T, 56>(vec, code_bytes, a, grid, st, pad);
+            case 64: return launch_vec<KIND, T, 64>(vec, code_bytes, a, grid, st, pad);
+            case 80: return launch_vec<KIND, T, 80>(vec, code_bytes, a, grid, st, pad);
+            case 96: return launch_vec<KIND, T, 96>(vec, code_bytes, a, grid, st, pad);
+            case 112: return launch_vec<KIND, T, 112>(vec, code_bytes, a, grid, st, pad);
+            case 128: return launch_vec<KIND, T, 128>(vec, code_bytes, a, grid, st, pad);
             default: return false;
             }
         } else {
@@ -100,19 +91,19 @@ bool launch_encode_mfma_t(int DP, bool vec, int code_bytes, const EncodeArgs& a,
         }
     } else {
         switch (DP) {
-        case 2: return launch_vec<KIND, T, 2>(vec, code_bytes, a, grid, st);
-        case 6: return launch_vec<KIND, T, 6>(vec, code_bytes, a, grid, st);
-        case 10: return launch_vec<KIND, T, 10>(vec, code_bytes, a, grid, st);
-        case 14: return launch_vec<KIND, T, 14>(vec, code_bytes, a, grid, st);
-        case 18: return launch_vec<KIND, T, 18>(vec, code_bytes, a, grid, st);
-        case 22: return launch_vec<KIND, T, 22>(vec, code_bytes, a, grid, st);
-        case 26: return launch_vec<KIND, T, 26>(vec, code_bytes, a, grid, st);
-        case 30: return launch_vec<KIND, T, 30>(vec, code_bytes, a, grid, st);
+        case 2: return launch_vec<KIND, T, 2>(vec, code_bytes, a, grid, st, pad);
+        case 6: return launch_vec<KIND, T, 6>(vec, code_bytes, a, grid, st, pad);
+        case 10: return launch_vec<KIND, T, 10>(vec, code_bytes, a, grid, st, pad);
+        case 14: return launch_vec<KIND, T, 14>(vec, code_bytes, a, grid, st, pad);
+        case 18: return launch_vec<KIND, T, 18>(vec, code_bytes, a, grid, st, pad);
+        case 22: return launch_vec<KIND, T, 22>(vec, code_bytes, a, grid, st, pad);
+        case 26: return launch_vec<KIND, T, 26>(vec, code_bytes, a, grid, st, pad);
+        case 30: return launch_vec<KIND, T, 30>(vec, code_bytes, a, grid, st, pad);
         default: return false;
         }
     }
 }
 
-template bool launch_encode_mfma_t<PQ_KIND, PQ_T, PQ_DPSET>(int, bool, int, const EncodeArgs&, dim3, hipStream_t);
+template bool launch_encode_mfma_t<PQ_KIND, PQ_T, PQ_DPSET>(int, bool, int, const EncodeArgs&, dim3, hipStream_t, unsigned);
 
 }  // namespace pqhip

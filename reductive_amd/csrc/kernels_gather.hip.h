@@ -1,140 +1,10 @@
-// kernels_basic.hip.h -- codebook preparation, the scalar "anchor" kernels (exact by
-// construction, any shape, any special value) and the reconstruct gather.
+// kernels_gather.hip.h -- the reconstruct gather (plain and lookup form) and the per-row rescale.  k_scale_rows is a
+// non-template kernel: include from exactly one translation unit (pqhip_opq.hip).
 #pragma once
 #include "common.hip.h"
 
 namespace pqhip {
 
-// ---------------------------------------------------------------------------------------------
-// Codebook preparation (runs once per pqhip_codebook_create)
-// ---------------------------------------------------------------------------------------------
-
-// cc[m][j] = c_j . c_j (linalg.rs:168; rule 1).  Entries j in [K, k_pad) are +inf so that a
-// padded centroid can never win the argmin.  One thread per (m, j).
-__global__ void k_centroid_norms(const float* __restrict__ cb, int M, int K, int dsub, int k_pad,
-                                 float* __restrict__ cc)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= M * k_pad) return;
-    const int m = idx / k_pad, j = idx % k_pad;
-    cc[idx] = (j < K) ? norm_unrolled_global(cb + ((int64_t)m * K + j) * dsub, dsub)
-                      : __builtin_inff();
-}
-
-// MFMA A-operand image of the codebook for v_mfma_f32_32x32x2_f32:
-//   frags[m][t][s][lane] = cb[m][32 t + (lane & 31)][2 s + (lane >> 5)]   (0 outside K / dsub)
-// so that a wave fetches the fragment of (tile t, k-step s) with one coalesced dword load.
-__global__ void k_build_frags(const float* __restrict__ cb, int M, int K, int dsub, int T, int S,
-                              float* __restrict__ frags)
-{
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)M * T * S * 64;
-    if (idx >= total) return;
-    const int lane = (int)(idx & 63);
-    int64_t r = idx >> 6;
-    const int s = (int)(r % S); r /= S;
-    const int t = (int)(r % T);
-    const int m = (int)(r / T);
-    const int j = 32 * t + (lane & 31);
-    const int k = 2 * s + (lane >> 5);
-    frags[idx] = (j < K && k < dsub) ? cb[((int64_t)m * K + j) * dsub + k] : 0.f;
-}
-
-// Transposed image for the small-codebook VALU kernel (kernels_smallk.hip.h):
-// cbt[m][k][j] = cb[m][j][k] for j < K, 0 for K <= j < KP
-__global__ void k_build_cbt(const float* __restrict__ cb, int M, int K, int dsub, int KP, float* __restrict__ cbt)
-{
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)M * dsub * KP) return;
-    const int j = (int)(idx % KP);
-    const int64_t r = idx / KP;
-    const int k = (int)(r % dsub), m = (int)(r / dsub);
-    cbt[idx] = (j < K) ? cb[((int64_t)m * K + j) * dsub + k] : 0.f;
-}
-
-// tells the fast paths whether every centroid norm is finite and far from overflow
-__global__ void k_check_norms(const float* __restrict__ cc, int M, int K, int k_pad, float big,
-                              int* __restrict__ flag_bad)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= M * k_pad) return;
-    const int j = idx % k_pad;
-    if (j < K && !(cc[idx] < big)) atomicOr(flag_bad, 1);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Scalar anchor encode: one thread per (row, subquantizer); literal CANON-F32 including the
-// three-operation distance and the NaN-aware total order.  Any M, K, dsub.  This is the
-// correctness anchor for the MFMA kernel and the fallback for shapes it does not cover.
-// primitives.rs:89-103 -> kmeans.rs:141-156 -> linalg.rs:167-176
-// ---------------------------------------------------------------------------------------------
-__device__ inline int assign_scalar(const float* __restrict__ xs, const float* __restrict__ cbm,
-                                    const float* __restrict__ ccm, int K, int dsub)
-{
-    const float xx = norm_unrolled_global(xs, dsub);
-    int best = 0;
-    float bestd = 0.f;
-    for (int j = 0; j < K; ++j) {
-        const float dp = chain_dot_global(xs, 1, cbm + (int64_t)j * dsub, 1, dsub);
-        const float t = fadd(xx, ccm[j]);
-        const float u = fadd(dp, dp);
-        const float d = fsub(t, u);
-        if (j == 0 || of_less(d, bestd)) { bestd = d; best = j; }
-    }
-    return best;
-}
-
-template <typename IdxT>
-__global__ void k_encode_scalar(const float* __restrict__ x, int64_t n, int64_t x_rs,
-                                IdxT* __restrict__ out, int64_t o_rs,
-                                const float* __restrict__ cb, const float* __restrict__ cc, int M,
-                                int K, int dsub, int k_pad)
-{
-    const int64_t total = n * M;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / M;
-        const int m = (int)(idx % M);
-        const int best = assign_scalar(x + row * x_rs + (int64_t)m * dsub,
-                                       cb + (int64_t)m * K * dsub, cc + (int64_t)m * k_pad, K, dsub);
-        out[row * o_rs + m] = (IdxT)best;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Scalar anchor rotation  out = x . Pm   (pq.rs:276 with Pm = P; pq.rs:324 with Pm = P^T).
-// One thread per output element, rule 2 chain.  Used for validation and odd shapes.
-// ---------------------------------------------------------------------------------------------
-__global__ void k_rotate_scalar(const float* __restrict__ x, int64_t n, int64_t x_rs,
-                                const float* __restrict__ Pm, int d, float* __restrict__ out,
-                                int64_t o_rs)
-{
-    const int64_t total = n * d;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / d;
-        const int c = (int)(idx % d);
-        out[row * o_rs + c] = chain_dot_global(x + row * x_rs, 1, Pm + c, d, d);
-    }
-}
-
-// Grouped codebooks (K > 256): codes[row][m] = index part of the minimum over the groups of the
-// 64-bit keys {ordered distance, global index} the MFMA kernel left per (row, virtual m).
-template <typename IdxT>
-__global__ __launch_bounds__(256) void k_merge_keys(const unsigned long long* __restrict__ keys, int64_t n,
-                                                    int M, int groups, IdxT* __restrict__ codes, int64_t o_rs)
-{
-    const int64_t total = n * M;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / M;
-        const int m = (int)(idx - row * M);
-        const unsigned long long* k = keys + (row * M + m) * groups;
-        unsigned long long best = k[0];
-        for (int g = 1; g < groups; ++g) best = (k[g] < best) ? k[g] : best;
-        codes[row * o_rs + m] = (IdxT)(unsigned)best;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Reconstruct gather  (primitives.rs:137-147, 169-172):

@@ -1,7 +1,7 @@
 // kernels_opq_fused2.hip.h -- OPQ encode in ONE kernel, second generation: rx = x.dot(P) (pq.rs:276) never leaves the
 // register file and BOTH stationary operands live in LDS.  (Template kernels, instantiated from opq_fused2_launch.hip.)
 //
-// The first generation (kernels_opq_fused.hip.h, round 2) staged x through LDS slabs, which left no room for the codebook
+// The first generation (round 2, removed from the library in round 4) staged x through LDS slabs, which left no room for the codebook
 // fragments next to the P block: they came from L2 and cost 10 % (36.5 ms against 34.5 for the two-kernel path).  Round 3's
 // rotation kernel (kernels_rotate8.hip.h) takes x straight from global memory into the MFMA operand registers, so LDS now
 // holds the 64-slot P block (76.8 KB at d = 300), the fragments of the block's NM = 64 / dsub sub-codebooks (61.4 KB at
@@ -12,11 +12,11 @@
 // encode epilogue of the first generation on the NM sub-vectors held in the accumulators.  Eight waves per workgroup (two per
 // SIMD, <= 256 VGPRs): the rotation half keeps the matrix pipe busy with two waves (the GATHER form of k_rotate_pblock8 shows it),
 // and both accumulator pairs, two burst buffers, the keys and two fragment sets are live around the seam between the halves.
-// Arithmetic is CANON-F32 throughout (see kernels_opq_fused.hip.h); rows that need the exact path are re-rotated by a scalar
+// Arithmetic is CANON-F32 throughout (see kernels_opq_common.hip.h); rows that need the exact path are re-rotated by a scalar
 // rule-2 chain (opq_rows_slow).  Instantiated for the burst structures of the shapes it is dispatched for
 // (opq_fused2_launch.h); everything else keeps the two-kernel path.
 #pragma once
-#include "kernels_opq_fused.hip.h"
+#include "kernels_opq_common.hip.h"
 #include "kernels_rotate8.hip.h"
 
 namespace pqhip {

@@ -35,27 +35,7 @@ struct Pair16Args {
     int64_t n_tiles;      // ceil(n / 32)
 };
 
-// fragp[p][s][lane = (i, h)] = A[i][2 s + h] of pair p (see the header); ccp[p][hh][r] = ||c_{2p+hh}[r]||^2
-__global__ void k_build_pair_frags(const float* __restrict__ cb, const float* __restrict__ cc, int M, int K, int dsub, int k_pad,
-                                   float* __restrict__ fragp, float* __restrict__ ccp)
-{
-    const int NP = (M + 1) / 2;
-    const int total = NP * dsub * 64;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total + NP * 32; idx += gridDim.x * blockDim.x) {
-        if (idx < total) {
-            const int lane = idx & 63, s = (idx >> 6) % dsub, p = (idx >> 6) / dsub;
-            const int i = lane & 31, h = lane >> 5;
-            const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
-            const int k = 2 * s + h, m = 2 * p + hh, kk = k - hh * dsub;
-            float v = 0.f;
-            if (m < M && r < K && kk >= 0 && kk < dsub) v = cb[((int64_t)m * K + r) * dsub + kk];
-            fragp[idx] = v;
-        } else {
-            const int q = idx - total, p = q >> 5, hh = (q >> 4) & 1, r = q & 15, m = 2 * p + hh;
-            ccp[q] = (m < M && r < K) ? cc[(int64_t)m * k_pad + r] : __builtin_inff();
-        }
-    }
-}
+// (k_build_pair_frags, the kernel that writes fragp / ccp, is a preparation kernel: kernels_prep.hip.h)
 
 template <int DSUB>
 __global__ __launch_bounds__(256, 3) void k_encode_pair16(Pair16Args a)

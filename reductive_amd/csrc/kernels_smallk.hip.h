@@ -7,7 +7,7 @@
 //   * one LANE owns one row (64 rows per wave); all M sub-vectors of the row are encoded by that lane,
 //     so x is read exactly once -- in whole row segments staged through a wave-private LDS slab;
 //   * the centroids never touch a vector register or LDS: the transposed image cbt[m][k][KP]
-//     (k_build_cbt, kernels_basic.hip.h) is read through the SCALAR cache and a pair of centroids is the scalar operand of
+//     (k_build_cbt, kernels_prep.hip.h) is read through the SCALAR cache and a pair of centroids is the scalar operand of
 //     one v_pk_fma_f32:  (dp_j, dp_j+1) = fma(x_k, (c_j[k], c_j+1[k]), (dp_j, dp_j+1)),  k ascending
 //     from +0 -- rule 2's chain, two centroids per instruction;
 //   * the distance is the literal three operations of linalg.rs:173-174 (packed), the argmin a

@@ -3,7 +3,7 @@
 // combinations listed below -- the shapes it is worth dispatching for; anything else keeps the two-kernel path.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "kernels_opq_fused.hip.h"
+#include "kernels_opq_common.hip.h"
 
 namespace pqhip {
 

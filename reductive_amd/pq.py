@@ -51,6 +51,26 @@ class _Ctx:
             _lib.lib().pqhip_ctx_destroy(self.handle)
             self.handle = None
 
+    def set_option(self, name, value):
+        """test / A-B knob (include/pqhip.h: pqhip_ctx_set_option), e.g. ("opq_fused", 0), ("kmeans_window_rows", 64)."""
+        rc = _lib.lib().pqhip_ctx_set_option(self.handle, name.encode(), int(value))
+        if rc != _lib.OK:
+            raise _lib.PqHipError(rc, "pqhip_ctx_set_option(%s)" % name)
+
+
+def set_option(name, value, ctx=None):
+    """pqhip_ctx_set_option on `ctx` (default: the process-wide context)."""
+    (ctx or default_ctx()).set_option(name, value)
+
+
+def launch_log(reset=False):
+    """Kernels the library launched from this thread since the last reset ("k_a + k_b x3"; include/pqhip.h)."""
+    L = _lib.lib()
+    text = L.pqhip_launch_log().decode()
+    if reset:
+        L.pqhip_launch_log_reset()
+    return text
+
 
 def default_ctx():
     global _default_ctx
@@ -466,7 +486,7 @@ class Pq:
 
     def set_encode_variant(self, variant):
         """test/bench knob (include/pqhip.h: pqhip_set_encode_variant): 0 auto, 1 scalar anchor kernel, 2 / 4 MFMA kernels,
-        5 fused OPQ kernel, 6 small-codebook VALU kernel, 7 pair kernel (K <= 16), 8 second fused OPQ kernel, 9 16x16x4 MFMA kernel."""
+        6 small-codebook VALU kernel, 7 pair kernel (K <= 16), 8 fused OPQ kernel, 9 16x16x4 MFMA kernel."""
         rc = _lib.lib().pqhip_set_encode_variant(self._cb(), variant)
         if rc != _lib.OK:
             raise _lib.PqHipError(rc)

@@ -73,10 +73,13 @@ const MIN_GPU_ROWS: usize = 4096;
 ///    destroyed when the last pin drops (eviction waits for users, users never wait for each other);
 ///  * key = (quantizer data pointer, element count, ORIGINAL projection data pointer or 0, M, K, dsub)
 ///    -- never the address of a temporary copy;
-///  * a hit is trusted only when a SAMPLED 64-bit content hash (first and last 4 KiB + 256 spread words
-///    of quantizers and projection: microseconds, not the ~70 us a full hash of 667 KB cost per call)
-///    and the GENERATION counter still match; `try_kmeans_iterations` and `train_step`, which rewrite
-///    centroids in place, bump the generation, so a stale image can never be served after them;
+///  * a hit is trusted only when the FULL 64-bit content hash of quantizers and projection (every byte is read:
+///    eight independent lanes, one AES round per 16 bytes with AES-NI, multiply-xorshift lanes otherwise --
+///    ~12 us for the 307 KB headline codebook) and the GENERATION counter still match.  Round 3 hashed a sample
+///    only; a dropped `Pq` whose allocation is reused by a quantizer that differs outside the sample was then
+///    served a stale image.  Every training exit bumps the generation (`TrainingExit` guard in
+///    `try_kmeans_iterations` -- CPU fall-through included -- and `train_step`; call `training_finished()` after
+///    any other in-place rewrite of centroids or projection), so a stale image can never be served after them;
 ///  * at most `CACHE_CAP` entries, least recently used dropped: device memory stays bounded.
 const CACHE_CAP: usize = 8;
 #[derive(PartialEq, Clone, Copy)]
@@ -101,30 +104,62 @@ fn handles() -> Option<&'static Handles> {
     }).as_ref()
 }
 
-/// FNV-1a over 8-byte words: change detection, not cryptography (content_hash of codebook_cache.hpp).
-fn content_hash(bytes: &[u8], mut h: u64) -> u64 {
-    let mut chunks = bytes.chunks_exact(8);
-    for c in &mut chunks {
-        h = (h ^ u64::from_ne_bytes(c.try_into().unwrap())).wrapping_mul(0x100000001b3);
-        h ^= h >> 29;
+/// content_hash of codebook_cache.hpp (same two forms; the values are process-local, so the forms need not agree).
+/// Portable form: eight 64-bit lanes, `h_j = xorshift((h_j ^ w) * prime)` per 64-byte block -- a bijection of the
+/// lane per step, so one changed word always changes its lane.
+fn content_hash_lanes(bytes: &[u8], mut h: u64) -> u64 {
+    const P: u64 = 0x100000001b3;
+    let mut l = [0u64; 8];
+    for j in 0..8 { l[j] = h ^ 0x9e3779b97f4a7c15u64.wrapping_mul(j as u64 + 1); }
+    let mut blocks = bytes.chunks_exact(64);
+    for b in &mut blocks {
+        for j in 0..8 {
+            let w = u64::from_ne_bytes(b[8 * j..8 * j + 8].try_into().unwrap());
+            l[j] = (l[j] ^ w).wrapping_mul(P);
+            l[j] ^= l[j] >> 29;
+        }
     }
-    for &b in chunks.remainder() { h = (h ^ b as u64).wrapping_mul(0x100000001b3); }
+    h ^= (bytes.len() as u64).wrapping_mul(P);
+    for j in 0..8 { h = (h ^ l[j]).wrapping_mul(P); h ^= h >> 29; }
+    let mut words = blocks.remainder().chunks_exact(8);
+    for c in &mut words { h = (h ^ u64::from_ne_bytes(c.try_into().unwrap())).wrapping_mul(P); h ^= h >> 29; }
+    for &b in words.remainder() { h = (h ^ b as u64).wrapping_mul(P); }
     h
 }
-/// sampled_hash of codebook_cache.hpp: everything when small, else head + tail + 256 spread words.
-fn sampled_hash(data: &[f32], mut h: u64) -> u64 {
-    const EDGE: usize = 4096; const WORDS: usize = 256;
-    let bytes = unsafe { std::slice::from_raw_parts(data.as_ptr() as *const u8, data.len() * 4) };
-    if bytes.len() <= 2 * EDGE + 8 * WORDS { return content_hash(bytes, h); }
-    h = content_hash(&bytes[..EDGE], h);
-    h = content_hash(&bytes[bytes.len() - EDGE..], h);
-    let step = ((bytes.len() - 2 * EDGE) / WORDS) & !7usize;
-    for i in 0..WORDS {
-        let o = EDGE + i * step;
-        h = (h ^ u64::from_ne_bytes(bytes[o..o + 8].try_into().unwrap())).wrapping_mul(0x100000001b3);
-        h ^= h >> 29;
+/// AES-NI form: eight 128-bit lanes, `state = AESENC(state ^ block, key)` (a permutation of state and of block).
+#[cfg(target_arch = "x86_64")]
+#[target_feature(enable = "aes,sse2")]
+unsafe fn content_hash_aes(bytes: &[u8], h: u64) -> u64 {
+    use std::arch::x86_64::*;
+    let key = _mm_set_epi64x(0xc2b2ae3d27d4eb4fu64 as i64, 0x9e3779b97f4a7c15u64 as i64);
+    let mut s = [_mm_setzero_si128(); 8];
+    for j in 0..8 { s[j] = _mm_set_epi64x((!h ^ ((j as u64) << 32)) as i64, h.wrapping_add(j as u64) as i64); }
+    let mut blocks = bytes.chunks_exact(128);
+    for b in &mut blocks {
+        for j in 0..8 {
+            let v = _mm_loadu_si128(b.as_ptr().add(16 * j) as *const __m128i);
+            s[j] = _mm_aesenc_si128(_mm_xor_si128(s[j], v), key);
+        }
     }
-    h
+    let mut acc = _mm_set_epi64x(h as i64, bytes.len() as i64);
+    for j in 0..8 { acc = _mm_aesenc_si128(_mm_xor_si128(acc, s[j]), key); }
+    let mut rest = blocks.remainder().chunks_exact(16);
+    for c in &mut rest { acc = _mm_aesenc_si128(_mm_xor_si128(acc, _mm_loadu_si128(c.as_ptr() as *const __m128i)), key); }
+    let tail = rest.remainder();
+    if !tail.is_empty() {
+        let mut t = [0u8; 16];
+        t[..tail.len()].copy_from_slice(tail);
+        acc = _mm_aesenc_si128(_mm_xor_si128(acc, _mm_loadu_si128(t.as_ptr() as *const __m128i)), key);
+    }
+    acc = _mm_aesenc_si128(_mm_aesenc_si128(acc, key), key);
+    (_mm_cvtsi128_si64(acc) ^ _mm_extract_epi64(acc, 1)) as u64
+}
+/// FULL content hash of an f32 array (every byte is read).
+fn content_hash(data: &[f32], h: u64) -> u64 {
+    let bytes = unsafe { std::slice::from_raw_parts(data.as_ptr() as *const u8, data.len() * 4) };
+    #[cfg(target_arch = "x86_64")]
+    { if std::is_x86_feature_detected!("aes") { return unsafe { content_hash_aes(bytes, h) }; } }
+    content_hash_lanes(bytes, h)
 }
 
 /// Pinned device image of (quantizers, projection).  `None` => no device / creation failed => CPU path.
@@ -137,8 +172,8 @@ fn codebook(q: ArrayView3<f32>, p: Option<ArrayView2<f32>>) -> Option<Arc<Image>
     let ps = p.as_ref().map(|p| p.as_standard_layout());
     let (m, k, dsub) = qs.dim();
     let key = Key { q: key_q, q_len: qs.len(), p: key_p, m, k, dsub };
-    let mut hash = sampled_hash(qs.as_slice()?, 0xcbf29ce484222325);
-    if let Some(ps) = &ps { hash = sampled_hash(ps.as_slice()?, hash); }
+    let mut hash = content_hash(qs.as_slice()?, 0xcbf29ce484222325);      // FULL contents
+    if let Some(ps) = &ps { hash = content_hash(ps.as_slice()?, hash); }
     let h = handles()?;
     let gen = h.generation.load(Ordering::Acquire);
     let stale;                                           // dropped (=> destroyed) after the lock is released
@@ -184,6 +219,14 @@ fn with_codebook<R>(q: ArrayView3<f32>, p: Option<ArrayView2<f32>>, f: impl FnOn
 
 /// Every entry point that rewrites quantizers or projections in place calls this.
 fn invalidate_images() { if let Some(h) = handles() { h.generation.fetch_add(1, Ordering::AcqRel); } }
+/// Public form for the patched trainers: call at EVERY exit of a training loop that rewrote centroids or the
+/// projection in place on the CPU (the fall-through after `try_kmeans_iterations` returned false, `Opq::train_iteration`'s
+/// `projection.assign(..)`): no device image created before it is served again.
+pub fn training_finished() { invalidate_images(); }
+/// Bumps the generation when it goes out of scope -- on every return path of a training entry point, including the
+/// early `return false` exits after which the caller's CPU loop rewrites the centroids in place.
+struct TrainingExit;
+impl Drop for TrainingExit { fn drop(&mut self) { invalidate_images(); } }
 
 fn same<A: 'static, B: 'static>() -> bool { TypeId::of::<A>() == TypeId::of::<B>() }
 
@@ -267,6 +310,7 @@ pub fn try_kmeans_iterations<A, S>(mut quantizers: ArrayViewMut3<A>, instances: 
     n_iterations: usize, losses: Option<&mut [A]>) -> bool
 where A: 'static + Copy, S: Data<Elem = A>,
 {
+    let _exit = TrainingExit;                              // generation bump on EVERY exit, CPU fall-through included
     if !same::<A, f32>() || instances.nrows() < MIN_GPU_ROWS || !quantizers.is_standard_layout() { return false; }
     let h = match handles() { Some(h) => h, None => return false };      // (no cache lock: serving calls keep running)
     let (m, k, dsub) = quantizers.dim();
@@ -277,8 +321,7 @@ where A: 'static + Copy, S: Data<Elem = A>,
     let rc = unsafe { pqhip_kmeans_iterations_f32(h.ctx.0, quantizers.as_mut_ptr() as *mut f32, m as i64, k as i64,
         dsub as i64, instances.as_ptr() as *const f32, instances.nrows() as i64, xs[0] as i64, xs[1] as i64,
         n_iterations as i32, loss_ptr) };
-    invalidate_images();                                   // the centroids were rewritten in place
-    rc == PQHIP_OK
+    rc == PQHIP_OK                                         // (`_exit` bumps the generation: the centroids were rewritten in place)
 }
 
 
@@ -297,6 +340,7 @@ impl ResidentInstances {
     /// In `Opq::train_iteration`: `if let Some(cross) = resident.train_step(projection.view(), centroids.view_mut())
     /// { let (u, _, vt) = cross.svd(true, true).unwrap(); projection.assign(&u.unwrap().dot(&vt.unwrap())); return; }`
     pub fn train_step(&self, projection: ArrayView2<f32>, mut quantizers: ArrayViewMut3<f32>) -> Option<ndarray::Array2<f32>> {
+        let _exit = TrainingExit;                          // generation bump on every exit of this step
         let h = handles()?;                                // (no cache lock: a training step never blocks serving calls)
         let (m, k, dsub) = quantizers.dim();
         if m * dsub != self.cols || !quantizers.is_standard_layout() { return None; }
@@ -305,7 +349,6 @@ impl ResidentInstances {
         let rc = unsafe { pqhip_opq_train_step_f32_dev(h.ctx.0, 0, quantizers.as_mut_ptr(), m as i64, k as i64, dsub as i64,
             p.as_ptr(), pqhip_matrix_device_ptr(self.m), self.rows as i64, self.cols as i64, cross.as_mut_ptr(),
             std::ptr::null_mut()) };
-        invalidate_images();                               // the quantizers were rewritten in place
         if rc == PQHIP_OK { Some(cross) } else { None }
     }
 }

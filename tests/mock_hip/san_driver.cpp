@@ -6,12 +6,22 @@
 // the C ABI promises".
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include <vector>
 #include "pqhip.h"
 
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+// PQHIP_TEST_SCRATCH_ROWS=<n> (read by THIS driver, not by the library): n-row OPQ scratch chunks through the context
+// option, so that every OPQ call walks many chunks and a remainder through one lease
+static bool apply_test_options(pqhip_ctx* ctx)
+{
+    const char* e = std::getenv("PQHIP_TEST_SCRATCH_ROWS");
+    if (e && pqhip_ctx_set_option(ctx, "opq_scratch_rows", std::atoll(e)) != PQHIP_OK) return false;
+    return pqhip_ctx_set_option(ctx, "no_such_option", 1) == PQHIP_EINVAL;
+}
 
 // "threads" mode (the ThreadSanitizer build runs only this): many host threads lease, grow and release the scratch
 // buffers of ONE OPQ codebook and ONE K > 256 codebook on both device slots at once, with sizes that force the pool to
@@ -21,6 +31,7 @@ static int threads_mode()
 {
     pqhip_ctx* ctx = nullptr;
     CHECK(pqhip_ctx_create(nullptr, 0, &ctx) == PQHIP_OK && pqhip_ctx_n_devices(ctx) == 2);
+    CHECK(apply_test_options(ctx));
     const int64_t M = 6, K = 64, dsub = 10, d = M * dsub;
     std::vector<float> q((size_t)(M * K * dsub), 0.25f), P((size_t)(d * d), 0.f);
     for (int64_t i = 0; i < d; ++i) P[(size_t)(i * d + i)] = 1.f;
@@ -76,6 +87,7 @@ int main(int argc, char** argv)
     CHECK(pqhip_device_count(&nd) == PQHIP_OK && nd == 2);
     pqhip_ctx* ctx = nullptr;
     CHECK(pqhip_ctx_create(nullptr, 0, &ctx) == PQHIP_OK && pqhip_ctx_n_devices(ctx) == 2);
+    CHECK(apply_test_options(ctx));
     const int64_t M = 15, K = 256, dsub = 20, d = M * dsub;
     std::vector<float> q((size_t)(M * K * dsub), 0.25f), P((size_t)(d * d), 0.f);
     for (int64_t i = 0; i < d; ++i) P[(size_t)(i * d + i)] = 1.f;

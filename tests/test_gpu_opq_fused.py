@@ -1,7 +1,7 @@
-"""Encode variant 5: OPQ rotation + encode fused in one kernel (kernels_opq_fused.hip.h; `rx = x.dot(P)`
-of pq.rs:276 never written to memory).  Codes must equal the oracle's -- i.e. the two-kernel path's --
-bit for bit, for every input: ragged row counts, ragged last column block, K < 256, special values
-(the exact path re-rotates flagged rows with the scalar rule-2 chain)."""
+"""OPQ rotation + encode fused in one kernel (encode variant 8, kernels_opq_fused2.hip.h; `rx = x.dot(P)` of
+pq.rs:276 never written to memory) and the two-kernel path that serves every other shape.  Codes must equal the
+oracle's bit for bit, for every input: ragged row counts, ragged last column block, K < 256, special values (the
+exact path re-rotates flagged rows with the scalar rule-2 chain)."""
 import numpy as np
 import pytest
 
@@ -21,98 +21,53 @@ def ra():
     return reductive_amd
 
 
-def _fused(ra, q, P):
-    pq = ra.Pq(P, q)
-    pq.set_encode_variant(5)
-    return pq
-
-
-SHAPES = [  # n, M, K, dsub
-    (200_003, 15, 256, 20),   # BASELINE configs[2] shape: 3 sub-vectors per 64-slot block, 5 blocks
-    (50_001, 16, 256, 16),    # 4 per block, no padding slots
-    (30_000, 24, 200, 10),    # 6 per block, K not a multiple of 32
-    (9_999, 2, 128, 32),      # 2 per block, T = 4
-    (20_000, 13, 256, 24),    # 2 per block, ragged last block (1 sub-vector)
-    (12_345, 12, 100, 4),     # 16 per block, only 12 exist; T = 4
-    (7_777, 26, 256, 12),     # 5 per block (60 slots), ragged last block, d = 312
-    (31, 15, 256, 20), (1, 15, 256, 20), (257, 8, 129, 8),
+SHAPES = [  # n, M, K, dsub -- OPQ shapes WITHOUT a fused instantiation: the auto variant takes rotation -> scratch -> encode
+    (50_001, 16, 128, 16),    # d = 256 has a fused instantiation for T = 8 only: K = 128 (T = 4) does not
+    (30_000, 24, 200, 10),    # 6 sub-vectors per 64-column block, K not a multiple of 32
+    (9_999, 2, 128, 32),      # T = 4
+    (20_000, 13, 256, 24),    # d = 312
+    (12_345, 12, 100, 4),     # short sub-vectors, T = 4
+    (7_777, 26, 256, 12),     # d = 312, dsub 12
+    (257, 8, 129, 8),
 ]
 
 
 @pytest.mark.parametrize("n,M,K,dsub", SHAPES)
-def test_fused_codes_equal_oracle(ra, n, M, K, dsub):
+def test_shapes_without_a_fused_kernel_take_the_two_kernel_path(ra, n, M, K, dsub):
+    """(These shapes ran the first-generation fused kernel, encode variant 5, until round 4 removed it.)  The launch log
+    names what ran: one rotation and one encode kernel, no fused kernel; codes equal the oracle's."""
     import torch
     d = M * dsub
     q = synth.normalish(6100 + d + K, (M, K, dsub))
     P = synth.orthonormal(6101 + d, d)
     x = synth.normalish(6102 + n, (n, d))
-    pq = _fused(ra, q, P)
+    pq = ra.Pq(P, q)
     want = orc.quantize_batch(q, x, projection=P, n_threads=8)
+    ra.launch_log(reset=True)
     got = pq.quantize_batch_device(torch.from_numpy(x).cuda())
     torch.cuda.synchronize()
-    assert pq.last_encode_kernel() == "k_opq_encode_fused"
+    log = ra.launch_log(reset=True)
+    assert "k_rotate_pblock" in log and "k_encode" in log and "fused" not in log, log
     assert got.cpu().numpy().tobytes() == want.tobytes()
-    assert pq.quantize_batch(x).tobytes() == want.tobytes()          # host-buffer entry point, same kernel
+    assert pq.quantize_batch(x).tobytes() == want.tobytes()          # host-buffer entry point
     # strided rows (row stride > d, 16-byte aligned)
     wide = torch.zeros((n, d + 12), device="cuda")
     wide[:, :d] = torch.from_numpy(x).cuda()
     assert pq.quantize_batch_device(wide[:, :d]).cpu().numpy().tobytes() == want.tobytes()
 
 
-def test_fused_special_values_take_the_exact_path(ra):
+def test_retired_variants_are_refused(ra):
+    pq = ra.Pq(None, synth.normalish(6310, (15, 256, 20)))
+    for v in (3, 5, 10, -1):
+        with pytest.raises(ra.PqHipError, match="invalid"):
+            pq.set_encode_variant(v)
     import torch
-    M, K, dsub = 15, 256, 20
-    d = M * dsub
-    q = synth.normalish(6200, (M, K, dsub))
-    P = synth.orthonormal(6201, d)
-    x = synth.normalish(6202, (4096, d))
-    # rows that coincide with centroids after the rotation (fast minimum can round below zero)
-    pick = synth.codes_u8(6203, (512, M), K).astype(np.int64)
-    cent = np.concatenate([q[m, pick[:, m]] for m in range(M)], axis=1)
-    x[100:612] = (cent.astype(np.float64) @ P.T.astype(np.float64)).astype(np.float32)
-    x[700, 3] = np.nan
-    x[701, 250] = np.inf
-    x[702] = -np.inf
-    x[703] *= np.float32(1e19)          # ||rx||^2 overflows the fast epilogue's range
-    x[704] = 0.0
-    x[705] = np.float32(1e-30)           # subnormal products
-    x[4095, 0] = np.nan                  # last row of the last tile
-    pq = _fused(ra, q, P)
-    with np.errstate(all="ignore"):
-        want = orc.quantize_batch(q, x, projection=P, n_threads=8)
-    got = pq.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy()
-    assert got.tobytes() == want.tobytes()
-
-
-def test_fused_refuses_shapes_without_an_instantiation(ra):
-    import torch
-    for M, K, dsub in ((5, 40, 7), (4, 16, 8), (2, 300, 8), (3, 256, 40)):   # odd dsub; T < 4; K > 256; dsub > 32
-        d = M * dsub
-        pq = _fused(ra, synth.normalish(6300 + d, (M, K, dsub)), synth.orthonormal(6301 + d, d))
-        x = torch.from_numpy(synth.normalish(6302, (100, d))).cuda()
-        with pytest.raises(ra.PqHipError, match="unsupported"):
-            pq.quantize_batch_device(x)
-    plain = ra.Pq(None, synth.normalish(6310, (15, 256, 20)))
-    plain.set_encode_variant(5)
+    pq.set_encode_variant(8)     # the fused OPQ kernel on a codebook without a projection
     with pytest.raises(ra.PqHipError, match="unsupported"):
-        plain.quantize_batch_device(torch.from_numpy(synth.normalish(6311, (100, 300))).cuda())
+        pq.quantize_batch_device(torch.from_numpy(synth.normalish(6311, (100, 300))).cuda())
 
 
-def test_fused_one_million_rows_every_code(ra):
-    import torch
-    M, K, dsub = 15, 256, 20
-    d = M * dsub
-    q = synth.normalish(6400, (M, K, dsub))
-    P = synth.orthonormal(6401, d)
-    g = torch.Generator(device="cuda").manual_seed(6402)
-    x = torch.empty((1_000_000, d), device="cuda").normal_(generator=g)
-    pq = _fused(ra, q, P)
-    got = pq.quantize_batch_device(x).cpu().numpy()
-    want = orc.quantize_batch(q, x.cpu().numpy(), projection=P, n_threads=16)
-    assert got.tobytes() == want.tobytes()
-
-
-# ---- second generation (encode variant 8, kernels_opq_fused2.hip.h): P block AND codebook fragments in LDS, x straight from
+# ---- the fused kernel (encode variant 8, kernels_opq_fused2.hip.h): P block AND codebook fragments in LDS, x straight from
 # global memory.  Instantiated for (dsub 20, d = 300-like: split, odd, tail) and (dsub 16: d = 256 and d = 320). --------------
 def _fused2(ra, q, P):
     pq = ra.Pq(P, q)

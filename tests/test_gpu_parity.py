@@ -118,7 +118,7 @@ def _has_mfma16(K, dsub):
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 9])
 def test_encode_matches_oracle(ra, shape, variant):
     n, M, K, dsub = shape
     if variant == 9 and not _has_mfma16(K, dsub):
@@ -155,7 +155,7 @@ def test_encode_special_values(ra):
     x[151] *= np.float32(3e19)          # xx overflows to inf
     x[160] *= np.float32(1e-30)         # subnormal products
     want = orc.quantize_batch(q, x)
-    for variant in (0, 1, 2, 3, 4, 9):
+    for variant in (0, 1, 2, 4, 9):
         got = _pq(ra, q, variant=variant).quantize_batch(x)
         assert got.tobytes() == want.tobytes(), variant
     # NaN / Inf / huge centroids: codebook leaves the fast path entirely
@@ -182,7 +182,7 @@ def test_encode_exact_and_near_ties(ra):
     x[192:256, :dsub] = big
     want = orc.quantize_batch(q, x)
     assert (want[:64, 0] == 7).all() and (want[64:128, 1] == 0).all()
-    for variant in (0, 1, 2, 3, 4, 9):
+    for variant in (0, 1, 2, 4, 9):
         assert _pq(ra, q, variant=variant).quantize_batch(x).tobytes() == want.tobytes(), variant
 
 
@@ -255,9 +255,9 @@ def test_opq_rotate_encode_and_reconstruct(ra):
 @pytest.mark.parametrize("d,M", [(256, 16), (260, 13), (320, 16), (324, 27), (330, 33), (352, 22), (356, 89),
                                  (384, 24), (512, 32), (515, 5), (768, 48), (1024, 64), (1300, 65)])
 def test_opq_rotation_dispatch_boundaries(ra, d, M):
-    """Every rotation-kernel choice of rotate_dev (LDS-resident P block up to d = 352, the slab
-    GEMM beyond, scalar-load variants for d % 4 != 0), on both sides of the rule-2 restart at
-    k = 256, for encode (x.P) and reconstruct (x.P^T)."""
+    """Every rotation-kernel choice of rotate_dev (pqhip_rotate.hip: k_rotate_pblock8 with a 64-column P block up to
+    d = 636, k_rotate_pblock9 where 64-column blocks pad much and, with 32-column blocks, up to d = 1,280, the slab GEMM
+    beyond and for d % 4 != 0), on both sides of the rule-2 restart at k = 256, for encode (x.P) and reconstruct (x.P^T)."""
     n, K = 203, 16
     dsub = d // M
     q = synth.normalish(91 + d, (M, K, dsub))
@@ -549,30 +549,45 @@ def test_config0_plumbing_shape_10k_rows(ra):
     assert pq.reconstruct_batch(codes).tobytes() == orc.reconstruct_batch(q, codes).tobytes()
 
 
-def test_opq_chunk_boundaries_of_a_multi_chunk_batch(ra):
-    """The two-kernel OPQ paths walk a large batch in scratch chunks that are whole rounds of the rotation grid
-    (1,179,648 rows on a 256-CU device, pqhip.hip opq_chunk_rows): 2.5 M rows = two full chunks and a remainder.
-    Codes and un-rotated reconstructions around both chunk boundaries, at the head and at the tail against the
-    oracle; every row through encode(decode(codes)) == codes."""
+@pytest.mark.parametrize("shape", [(15, 20, "opq_fused"), (48, 16, None)])
+def test_opq_chunk_boundaries_of_a_multi_chunk_batch(ra, ctx_options, shape):
+    """The TWO-KERNEL OPQ paths (rotation -> leased scratch -> encode; gather -> scratch -> rotation) walk a large batch in
+    scratch chunks that are whole rounds of the rotation grid (1,179,648 rows on a 256-CU device, pqhip_opq.hip
+    opq_chunk_rows): 2.5 M rows = two full chunks and a remainder.  The paths are FORCED -- at d = 300 the default is the
+    fused kernel (one launch, no chunks), so the context options "opq_fused" / "opq_gather_rotation" are cleared; d = 768 /
+    M = 48 (the size of BASELINE configs[4]) has no fused encode instantiation and takes the chunk loop by itself -- and the
+    launch log must show one rotation and one encode launch per chunk.  Codes and un-rotated reconstructions around both
+    chunk boundaries, at the head and at the tail against the oracle; every row through encode(decode(codes)) == codes."""
     import torch
-    M, K, dsub = 15, 256, 20
+    M, dsub, opt = shape
+    K = 256
     d, n = M * dsub, 2_500_000
-    q = synth.normalish(43, (M, K, dsub))
-    P = synth.orthonormal(44, d)
+    q = synth.normalish(43 + M, (M, K, dsub))
+    P = synth.orthonormal(44 + M, d)
     pq = _pq(ra, q, P)
+    if opt:
+        ctx_options(opt, 0)
+    ctx_options("opq_gather_rotation", 0)
     g = torch.Generator(device="cuda").manual_seed(47)
     x = torch.randn((n, d), device="cuda", dtype=torch.float32, generator=g)
+    ra.launch_log(reset=True)
     codes = pq.quantize_batch_device(x)
+    log = ra.launch_log(reset=True)
+    assert "k_rotate_pblock" in log and " x3" in log and "k_encode_mfma16 x3" in log and "fused" not in log, log
     rec = pq.reconstruct_batch_device(codes, check=True)
-    cores = os.cpu_count() or 8
+    log = ra.launch_log(reset=True)
+    assert "k_reconstruct x3" in log and "k_rotate_pblock" in log and "gather" not in log, log
+    cores = min(os.cpu_count() or 8, 16)
     chunk = 1_179_648
-    for r0 in (0, chunk - 3000, 2 * chunk - 3000, n - 6000):
-        xs = x[r0:r0 + 6000].cpu().numpy()
+    ns = 6000 if d == 300 else 2000
+    for r0 in (0, chunk - ns // 2, 2 * chunk - ns // 2, n - ns):
+        xs = x[r0:r0 + ns].cpu().numpy()
         want = orc.quantize_batch(q, xs, projection=P, n_threads=cores)
-        assert codes[r0:r0 + 6000].cpu().numpy().tobytes() == want.tobytes(), r0
+        assert codes[r0:r0 + ns].cpu().numpy().tobytes() == want.tobytes(), r0
         ref = orc.reconstruct_batch(q, want, projection=P)
-        got = rec[r0:r0 + 6000].cpu().numpy()
+        got = rec[r0:r0 + ns].cpu().numpy()
         assert np.abs(got - ref).max() <= REL_TOL * np.abs(ref).max(), r0
+    del x
     # size-independent: the reconstruction of a code row encodes back to that code row (a rotated centroid is its own
     # nearest centroid after the inverse rotation up to rounding; compare where the round trip is well separated)
     again = pq.quantize_batch_device(rec)
@@ -639,7 +654,7 @@ def test_shape_sweep_all_kernel_instantiations(ra):
         q = synth.normalish(5000 + i, (M, K, dsub))
         x = synth.normalish(6000 + i, (n, M * dsub))
         want = orc.quantize_batch(q, x)
-        for variant in (0, 2, 3, 4) + ((9,) if _has_mfma16(K, dsub) else ()):
+        for variant in (0, 2, 4) + ((9,) if _has_mfma16(K, dsub) else ()):
             got = _pq(ra, q, variant=variant).quantize_batch(x)
             assert got.tobytes() == want.tobytes(), (M, K, dsub, n, variant)
     # device rows that start off the 16-byte grid (row stride not a multiple of 4 floats): the same
@@ -743,7 +758,7 @@ def test_trained_codebook_and_opq_at_scale(ra):
             for j in np.unique(codes[:, m]):
                 q[m, j] = sub[codes[:, m] == j].mean(0)
     want = orc.quantize_batch(q, x, n_threads=16)
-    for variant in (0, 3):
+    for variant in (0, 4):
         got = _pq(ra, q, variant=variant).quantize_batch(x)
         assert got.tobytes() == want.tobytes(), variant
     P = synth.orthonormal(9202, d)
@@ -858,10 +873,10 @@ def test_kmeans_iterations_match_oracle(ra, shape):
     assert q0.tobytes() == _km_inputs(n, M, K, dsub, 700 + n)[0].tobytes()   # inputs untouched
 
 
-def test_kmeans_many_row_windows(ra, monkeypatch):
+def test_kmeans_many_row_windows(ra, ctx_options):
     """The update runs window by window (overlapped with the assignment of the next window); with
     the window shrunk to 64 rows the carried chains and counts cross dozens of windows."""
-    monkeypatch.setenv("PQHIP_DEBUG_KM_WINROWS", "64")
+    ctx_options("kmeans_window_rows", 64)
     for (n, M, K, dsub) in [(5000, 15, 256, 20), (1999, 3, 5, 7), (130, 2, 300, 6), (700, 2, 4, 68), (900, 1, 3, 300)]:
         q0, x = _km_inputs(n, M, K, dsub, 900 + n)
         want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=2)
@@ -869,9 +884,9 @@ def test_kmeans_many_row_windows(ra, monkeypatch):
         assert got_q.tobytes() == want_q.tobytes()
         assert got_loss.tobytes() == want_loss.tobytes()
         # the lane-per-chain form of the walk (used for very wide sub-vectors) on the same inputs
-        monkeypatch.setenv("PQHIP_DEBUG_KM_LANEFORM", "1")
+        ctx_options("kmeans_lane_form", 1)
         got_q, got_loss = ra.kmeans_iterations(q0, x, n_iterations=2)
-        monkeypatch.delenv("PQHIP_DEBUG_KM_LANEFORM")
+        ctx_options("kmeans_lane_form", 0)
         assert got_q.tobytes() == want_q.tobytes()
         assert got_loss.tobytes() == want_loss.tobytes()
 
@@ -920,17 +935,17 @@ def test_kmeans_special_values_and_empty_clusters(ra):
     assert got_q4.tobytes() == want_q4.tobytes() and got_loss4.tobytes() == want_loss4.tobytes()
 
 
-def test_kmeans_graph_replay_equals_eager_loop(ra, monkeypatch):
+def test_kmeans_graph_replay_equals_eager_loop(ra, ctx_options):
     """Small training sets run all iterations but the last as one replayed hipGraph: same bits as
-    the eager loop (PQHIP_DEBUG_KM_NOGRAPH) and as the oracle, for u8 and for odd shapes."""
+    the eager loop (context option "kmeans_no_graph") and as the oracle, for u8 and for odd shapes."""
     for (n, M, K, dsub, iters) in [(4000, 15, 256, 20, 12), (777, 3, 5, 7, 6), (2000, 2, 16, 40, 4)]:
         q0, x = _km_inputs(n, M, K, dsub, 2200 + n)
         want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=iters, n_threads=8)
         got_q, got_loss = ra.kmeans_iterations(q0, x, n_iterations=iters)
         assert got_q.tobytes() == want_q.tobytes() and got_loss.tobytes() == want_loss.tobytes()
-        monkeypatch.setenv("PQHIP_DEBUG_KM_NOGRAPH", "1")
+        ctx_options("kmeans_no_graph", 1)
         eager_q, eager_loss = ra.kmeans_iterations(q0, x, n_iterations=iters)
-        monkeypatch.delenv("PQHIP_DEBUG_KM_NOGRAPH")
+        ctx_options("kmeans_no_graph", 0)
         assert eager_q.tobytes() == want_q.tobytes() and eager_loss.tobytes() == want_loss.tobytes()
 
 

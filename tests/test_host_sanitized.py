@@ -23,7 +23,7 @@ def test_host_logic_under_asan_ubsan_with_mock_hip():
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     # twice: with the library's own chunk sizes, and with 1,000-row OPQ scratch chunks so that every OPQ call of the
     # driver walks many chunks and a remainder through one lease (the chunk loop of quantize_dev_impl / reconstruct_dev_impl)
-    for extra in ({}, {"PQHIP_DEBUG_SCRATCH_ROWS": "1000"}):
+    for extra in ({}, {"PQHIP_TEST_SCRATCH_ROWS": "1000"}):
         run = subprocess.run([os.path.join(MOCK, "build", "san_driver")], capture_output=True, text=True,
                              env=dict(env, **extra), timeout=900)
         out = run.stdout + run.stderr
@@ -41,7 +41,7 @@ def test_host_threads_under_tsan_with_mock_hip():
     build = subprocess.run(["make", "-C", MOCK, "-s", "-j8", "SAN=" + san, "B=build_tsan"], capture_output=True, text=True, timeout=1500)
     assert build.returncode == 0, build.stderr[-3000:]
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
-    for extra in ({}, {"PQHIP_DEBUG_SCRATCH_ROWS": "1000"}):
+    for extra in ({}, {"PQHIP_TEST_SCRATCH_ROWS": "1000"}):
         run = subprocess.run([os.path.join(MOCK, "build_tsan", "san_driver"), "threads"], capture_output=True, text=True,
                              env=dict(env, **extra), timeout=900)
         out = run.stdout + run.stderr
