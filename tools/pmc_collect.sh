@@ -3,6 +3,10 @@
 # record, one `rocprofv3 --kernel-trace --stats` pass and two SEPARATE counter passes (FETCH_SIZE,
 # WRITE_SIZE; never combined with other trace domains), then tools/pmc_summarize.py turns them into
 # profiles/pmc_traffic.json entries stamped with the kernel-source hash bench.py checks.
+# Round 4: every pass runs the DRIVER's command (`--steps 20 --warmup 5`), one run per
+# workload, and the summary averages the dominant kernel over the 20 timed launches only (per-dispatch records
+# of the kernel trace), next to the HIP-event mean bench.py measured in that very run; for the encode workloads
+# a fourth run on the diagnostic build (libpqhip_diag.so, if present) records the in-kernel clock.
 # usage: tools/pmc_collect.sh <tag> [workload ...]      (default: the four single-GPU BASELINE configs + lookup + adc_scan)
 set -u
 TAG=$1; shift
@@ -19,10 +23,16 @@ for W in $WL; do
     smallk) ARGS="--workload encode --d 128 --m 16 --k 16";;
     *) ARGS="--workload $W";;
   esac
-  CMD="$R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-sub-configs"
+  CMD="$R/bench.py $ARGS --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-sub-configs"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$W/stats -- python3 $CMD > $OUT/$W.bench.json 2> $OUT/$W.stats.err || echo "stats pass failed: $W"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/$W/fetch -- python3 $CMD > /dev/null 2> $OUT/$W.fetch.err || echo "fetch pass failed: $W"
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/$W/write -- python3 $CMD > /dev/null 2> $OUT/$W.write.err || echo "write pass failed: $W"
+  case $W in
+    encode|encode_d768|opq_encode)
+      if [ -f $R/reductive_amd/libpqhip_diag.so ]; then
+        PQHIP_LIB=$R/reductive_amd/libpqhip_diag.so PQHIP_DEBUG_ENC_STAMP=1 PQHIP_DEBUG_FUSED_STAMP=1 python3 $CMD > /dev/null 2> $OUT/$W.clock.err || echo "clock pass failed: $W"
+      fi;;
+  esac
   echo "done $W"
 done
 python3 $R/tools/pmc_summarize.py $OUT $WL > $OUT/pmc_traffic.json

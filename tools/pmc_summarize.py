@@ -22,6 +22,29 @@ def stats(d):
                 best = r
     return best
 
+def timed_launches(d, kernel, n_timed):
+    """durations (ns) of the LAST n_timed dispatches of `kernel` in the kernel trace of the stats pass: the timed
+    steps of the bench run, without the warm-up launches (the first of which is cold)"""
+    rows = []
+    for p in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(p)):
+            if r["Kernel_Name"] == kernel:
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows.sort()
+    return [dur for _, dur in rows][-n_timed:]
+
+
+def clock_mhz(path):
+    """mean of the 'clock NNNN MHz' figures the diagnostic build printed (in-kernel s_memtime / s_memrealtime)"""
+    import re
+    try:
+        v = [float(m) for m in re.findall(r"clock (\d+) MHz", open(path).read())]
+    except OSError:
+        return None
+    v = [x for x in v if x > 0]
+    return sum(v[-20:]) / len(v[-20:]) if v else None
+
+
 def counter(d, name, kernel):
     vals = []
     for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -64,8 +87,11 @@ for w in wls:
     wr = counter(os.path.join(out_dir, w, "write"), "WRITE_SIZE", kern)
     if not f or not wr:
         print("no counters for", w, file=sys.stderr); continue
-    # skip the warm-up dispatch(es): keep the last 3 (the timed steps)
-    f, wr = f[-3:], wr[-3:]
+    # skip the warm-up dispatches: keep the timed steps
+    per_step_launches = max(1, int(s["Calls"]) // (b["steps"] + b["warmup"]))
+    n_timed = b["steps"] * per_step_launches
+    f, wr = f[-n_timed:], wr[-n_timed:]
+    tl = timed_launches(os.path.join(out_dir, w, "stats"), kern, n_timed)
     c = b["config"]
     fetch_b = sum(f) / len(f) * 1024 * 2
     write_b = sum(wr) / len(wr) * 1024
@@ -76,7 +102,12 @@ for w in wls:
     alg = b["roofline"].get("algorithmic_bytes_per_vector", 0) * c["rows_per_gpu"]
     entries[key] = {"workload": wl_name, "rows": c["rows_per_gpu"], "kernel": kern[:120], "calls_in_stats_pass": int(s["Calls"]),
                     "avg_launch_ms_stats_pass": float(s["AverageNs"]) / 1e6,
+                    "avg_launch_ms_timed_launches": (sum(tl) / len(tl) / 1e6) if tl else None,
+                    "min_max_launch_ms_timed_launches": [min(tl) / 1e6, max(tl) / 1e6] if tl else None,
+                    "timed_launches": len(tl),
                     "bench_avg_launch_ms_hip_events": b["roofline"]["avg_launch_ms"],
+                    "bench_ms_per_step_same_run": b["ms_per_step"],
+                    "in_kernel_clock_mhz_diag_pass": clock_mhz(os.path.join(out_dir, w + ".clock.err")),
                     "fetch_bytes": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
                     "algorithmic_bytes": alg, "ratio": (fetch_b + write_b) / alg if alg else None,
                     "dispatches_averaged": len(f), "source_hash": bench.source_hash()}
