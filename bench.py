@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--queries", type=int, default=1, help="adc_scan workload: queries scanned per step (8 share one pass over the codes)")
     ap.add_argument("--record-bytes", type=int, default=None, help="lookup workload: interleaved records of this many bytes (codes + scale of a row together) instead of a code matrix and a scale vector")
     ap.add_argument("--lookup-codes", type=int, default=10_000_000, help="lookup workload: rows of the resident code matrix")
+    ap.add_argument("--fast-cross", action="store_true",
+                    help="opq_train workload: X^T.R as a plain split-K product (context option cross_product_exact = 0: float tolerance, no per-block partials)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise sharding/reduction/printing only (CPU, gloo); no GPU work")
     return ap.parse_args()
@@ -253,6 +255,8 @@ class Bench:
             from reductive_amd.pq import opq_train_step
             P0 = synth.orthonormal(44, d)
             state = {"q": q0}
+            self.ctx.set_option("cross_product_exact", 0 if args.fast_cross else 1)
+            extra["cross_product"] = "float tolerance (split-K)" if args.fast_cross else "exact (rule 2: 256-row blocks added in row order)"
 
             def step():
                 state["q"], state["cross"] = opq_train_step(state["q"], P0, src, ctx=self.ctx)

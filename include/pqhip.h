@@ -99,8 +99,11 @@ int32_t pqhip_reconstruct_batch_f32(pqhip_codebook *cb, const void *codes, int32
 /*
  * DEVICE-resident entry points (inputs/outputs already in the HBM of device `device_slot` of the
  * ctx; unit column stride; row strides in elements).  Asynchronous on `stream` (a hipStream_t
- * passed as void*, NULL = the device's default stream); the caller synchronises.  Only u8 and
- * u32 codes.  `scratch` for the OPQ variants is managed inside the codebook handle.
+ * passed as void*, NULL = the device's default stream); the caller synchronises.  code_bytes in
+ * {1, 2, 4, 8} as for the host entry points (traits.rs:77-88 is generic over the index type): the
+ * kernels produce / consume u8 and u32 codes, 2- and 8-byte matrices are converted on the device
+ * through a leased scratch matrix (the row-lookup, ADC and k-means entry points take 1- and 4-byte
+ * codes only).  Scratch for the OPQ variants is managed inside the codebook handle.
  */
 int32_t pqhip_quantize_batch_f32_dev(pqhip_codebook *cb, int32_t device_slot, const float *d_x,
                                      int64_t n_rows, int64_t x_row_stride, void *d_codes,
@@ -289,7 +292,10 @@ int32_t pqhip_set_rotation_variant(int32_t variant);
  *   "opq_scratch_rows"     rows per chunk of the two-kernel OPQ paths (0 = whole rounds of the rotation grid)
  *   "opq_fused"            0 = OPQ encode as rotation -> scratch -> encode (default 1; PQHIP_FUSED2_OPQ=0 presets 0)
  *   "opq_gather_rotation"  0 = OPQ reconstruct as gather -> scratch -> rotation (default 1)
- *   "adc_single_query"     1 = one scan pass per query (default 0: 8 / 4 queries share a pass)                  */
+ *   "adc_single_query"     1 = one scan pass per query (default 0: 8 / 4 queries share a pass)
+ *   "cross_product_exact"  0 = X^T.R of the OPQ training step / pqhip_at_dot_b_f32_dev as a plain split-K product:
+ *                          within 1e-5 relative of the exact rule-2 result, no per-block partial matrices (default 1)
+ *   "cross_product_group_bytes"  workspace of partial matrices per launch group (0 = 4 GiB)                      */
 int32_t pqhip_ctx_set_option(pqhip_ctx *ctx, const char *name, int64_t value);
 /* Launch log of the calling thread: every kernel the library launches is noted by name; pqhip_launch_log() renders
  * "k_a + k_b x3 + ..." (distinct names in first-launch order with counts; valid until the thread's next call of

@@ -1,5 +1,5 @@
-// kernels_gather.hip.h -- the reconstruct gather (plain and lookup form) and the per-row rescale.  k_scale_rows is a
-// non-template kernel: include from exactly one translation unit (pqhip_opq.hip).
+// kernels_gather.hip.h -- the reconstruct gather (plain and lookup form), the per-row rescale and the index-width
+// conversion of 2- / 8-byte codes.  k_scale_rows is a non-template kernel: include from exactly one translation unit (pqhip_opq.hip).
 #pragma once
 #include "common.hip.h"
 
@@ -223,6 +223,25 @@ __global__ __launch_bounds__(256) void k_scale_rows(float* __restrict__ out, int
         if (src < 0 || src >= n_codes) src = 0;
         out[row * o_rs + c] = fmul(out[row * o_rs + c], sel_scales[src * s_rs]);
     }
+}
+
+// Index-width conversion for the device entry points with 2- and 8-byte codes (the reference is generic over the index
+// type I, traits.rs:77-88; the kernels produce / consume u8 and u32): dst[row][m] = (Dst)src[row][m].  `K` > 0: a source
+// value >= K raises *err BEFORE it is narrowed (reconstruct: index_axis panic, primitives.rs:146) and is clamped to K.
+template <typename Src, typename Dst>
+__global__ __launch_bounds__(256) void k_convert_codes(const Src* __restrict__ src, int64_t s_rs, Dst* __restrict__ dst, int64_t d_rs,
+                                                       int64_t n, int M, unsigned long long K, int* __restrict__ err)
+{
+    const int64_t total = n * M;
+    bool bad = false;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / M;
+        const int m = (int)(idx - row * M);
+        unsigned long long v = (unsigned long long)src[row * s_rs + m];
+        if (K && v >= K) { bad = true; v = K; }
+        dst[row * d_rs + m] = (Dst)v;
+    }
+    if (bad && err) atomicOr(err, 1);
 }
 
 }  // namespace pqhip

@@ -338,102 +338,6 @@ __global__ __launch_bounds__(256) void k_km_loss(const float* __restrict__ x, in
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// C = A^T . B over the rows (`instances.t().dot(&reconstructed)`, opq.rs:191) with rule-2
-// arithmetic: per output element one fmaf chain over the rows of each 256-row block, the block
-// results added to C in block order.  The chains of different blocks are independent, so phase 1
-// runs them all at once on the matrix cores (one wave = one 256-row block x one 64 x 64 macro tile
-// = 4 MFMA tiles, operands straight from HBM/L2: lane (i, h) of a k-step reads A[r0 + 2s + h][i],
-// 128 contiguous bytes per half-wave) and leaves one partial matrix per block; phase 2 folds the
-// partials in block order with one rounded add each (one lane per output element).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_atb_blocks(const float* __restrict__ A, int64_t a_rs, int da,
-                                                    const float* __restrict__ B, int64_t b_rs, int db,
-                                                    int64_t n, int64_t block0, int nblocks, int ti, int tj,
-                                                    int pa, int pb, float* __restrict__ part)
-{
-    // grid.x = ceil(nblocks / 4) * ti * tj; wave w of workgroup g: block 4 * (g / (ti*tj)) + w.
-    // Operands are fetched 16 rows x 64 columns at a time with 16-byte loads (lane = row l >> 4 (+4 i),
-    // columns 4 (l & 15) ..: whole 256-byte row segments) and handed to the MFMA layout through a
-    // wave-private LDS slab: with one dword load per operand and k-step the address unit, not the
-    // matrix core, was the bound (512 load instructions per 512 MFMAs).
-    constexpr int SR = 16;            // rows per slab = 8 k-steps
-    constexpr int XS = 68;            // slab row stride in floats (272 B: 16-byte aligned, conflict-free reads)
-    __shared__ __attribute__((aligned(16))) float slab[4][2][2][SR][XS];  // [wave][buffer][A|B][row][col]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int mt = blockIdx.x % (ti * tj);
-    const int bl = 4 * (blockIdx.x / (ti * tj)) + wave;  // block inside this group of blocks
-    if (bl >= nblocks) return;                           // (no workgroup barrier below)
-    const int I = mt / tj, J = mt - I * tj;
-    const int j = lane & 31, h = lane >> 5;
-    const int64_t r0 = (block0 + bl) * (int64_t)kKC;
-    const int lr = lane >> 4, lc = 4 * (lane & 15);      // staging role: rows lr + 4 i, columns lc .. lc + 3
-    const int ca = 64 * I + lc, cb = 64 * J + lc;
-    const bool va = ca < da, vb = cb < db;               // da, db multiples of 4 or guarded per element below
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
-    f32x4 sa[4], sb[4];
-    auto fetch = [&](int slab_i) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t r = r0 + (int64_t)slab_i * SR + lr + 4 * i;
-            f32x4 qa = {0.f, 0.f, 0.f, 0.f}, qb = {0.f, 0.f, 0.f, 0.f};
-            if (r < n) {
-                const float* ar = A + r * a_rs + ca;
-                const float* br = B + r * b_rs + cb;
-                if (va) { if (ca + 4 <= da) qa = *reinterpret_cast<const f32x4_u*>(ar);
-                          else { for (int e = 0; e < 4; ++e) if (ca + e < da) qa[e] = ar[e]; } }
-                if (vb) { if (cb + 4 <= db) qb = *reinterpret_cast<const f32x4_u*>(br);
-                          else { for (int e = 0; e < 4; ++e) if (cb + e < db) qb[e] = br[e]; } }
-            }
-            sa[i] = qa; sb[i] = qb;
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&slab[wave][buf][0][lr + 4 * i][lc]) = sa[i];
-            *reinterpret_cast<f32x4*>(&slab[wave][buf][1][lr + 4 * i][lc]) = sb[i];
-        }
-    };
-    constexpr int NS = kKC / SR;  // 16 slabs per block
-    fetch(0);
-    stash(0);
-    for (int sl = 0; sl < NS; ++sl) {
-        const int buf = sl & 1;
-        if (sl + 1 < NS) fetch(sl + 1);  // next slab in flight behind this slab's 32 MFMAs
-#pragma unroll
-        for (int u = 0; u < SR / 2; ++u) {
-            const float a0 = slab[wave][buf][0][2 * u + h][j], a1 = slab[wave][buf][0][2 * u + h][32 + j];
-            const float b0 = slab[wave][buf][1][2 * u + h][j], b1 = slab[wave][buf][1][2 * u + h][32 + j];
-            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c00, 0, 0, 0);
-            c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c01, 0, 0, 0);
-            c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c10, 0, 0, 0);
-            c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c11, 0, 0, 0);
-        }
-        if (sl + 1 < NS) stash(buf ^ 1);
-    }
-    float* p = part + (int64_t)bl * pa * pb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        p[(int64_t)(64 * I + i) * pb + 64 * J + j] = c00[r];
-        p[(int64_t)(64 * I + i) * pb + 64 * J + 32 + j] = c01[r];
-        p[(int64_t)(64 * I + 32 + i) * pb + 64 * J + j] = c10[r];
-        p[(int64_t)(64 * I + 32 + i) * pb + 64 * J + 32 + j] = c11[r];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_atb_fold(const float* __restrict__ part, int nblocks, int pa, int pb,
-                                                  int first, float* __restrict__ C)
-{
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)pa * pb;
-    if (idx >= total) return;
-    float c = first ? part[idx] : C[idx];
-#pragma unroll 8
-    for (int b = first ? 1 : 0; b < nblocks; ++b) c = fadd(c, part[(int64_t)b * total + idx]);
-    C[idx] = c;
-}
+// (C = A^T . B of the OPQ training step: kernels_atb.hip.h)
 
 }  // namespace pqhip

@@ -81,6 +81,8 @@ struct Options {
     std::atomic<int64_t> opq_fused{1};              // 0: OPQ encode as rotation -> scratch -> encode
     std::atomic<int64_t> opq_gather_rotation{1};    // 0: OPQ reconstruct as gather -> scratch -> rotation
     std::atomic<int64_t> adc_single_query{0};       // 1: one scan pass per query
+    std::atomic<int64_t> cross_product_exact{1};    // 0: X^T.R as a plain split-K product (float tolerance, no per-block partials)
+    std::atomic<int64_t> cross_product_group_bytes{0};   // workspace of partial matrices per launch group (0: 4 GiB; tests shrink it)
 };
 
 struct Diag {

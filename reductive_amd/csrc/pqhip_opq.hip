@@ -268,6 +268,29 @@ int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, 
     return PQHIP_OK;
 }
 
+// 2- and 8-byte codes (u16 / u64 / usize index types, traits.rs:77-88): the kernels work on u8 (K <= 256) or u32 codes in a
+// leased scratch matrix, k_convert_codes widens / narrows between it and the caller's matrix, chunk by chunk.
+template <typename Fn>
+static int32_t with_converted_codes(pqhip_codebook* cb, int slot, int64_t n, hipStream_t st, int dev_bytes, Fn fn)
+{
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (1ll << 30) / (cb->M * dev_bytes)));
+    ScratchLease tmp(cb, slot, st);
+    PQCHK(tmp.acquire((size_t)chunk * cb->M * dev_bytes));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) PQCHK(fn(tmp.ptr(), r0, std::min<int64_t>(chunk, n - r0)));
+    return PQHIP_OK;
+}
+
+template <typename Src, typename Dst>
+static int32_t convert_codes(const void* src, int64_t s_rs, void* dst, int64_t d_rs, int64_t rows, int M, uint64_t K, int* err, hipStream_t st)
+{
+    const unsigned g = (unsigned)std::min<int64_t>((rows * M + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL((k_convert_codes<Src, Dst>), dim3(g), dim3(256), 0, st, (const Src*)src, s_rs, (Dst*)dst, d_rs, rows, M,
+                       (unsigned long long)K, err);
+    HIPCHK(hipGetLastError());
+    note_kernel("k_convert_codes");
+    return PQHIP_OK;
+}
+
 }  // namespace pqh
 
 using namespace pqh;
@@ -282,11 +305,24 @@ int32_t pqhip_quantize_batch_f32_dev(pqhip_codebook* cb, int32_t slot, const flo
     if (!cb || n < 0) return PQHIP_EINVAL;
     if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
     if (n > 0 && (!d_x || !d_codes)) return PQHIP_EINVAL;
-    if (code_bytes != 1 && code_bytes != 4) return PQHIP_EUNSUPPORTED;
-    if (code_bytes == 1 && cb->K > 256) return PQHIP_EINDEX_WIDTH;  // primitives.rs:31-34
+    if (code_bytes != 1 && code_bytes != 2 && code_bytes != 4 && code_bytes != 8) return PQHIP_EUNSUPPORTED;
+    // primitives.rs:31-34 "Cannot store centroids in quantizer index type"
+    if (code_bytes < 8 && (uint64_t)(cb->K - 1) > ((1ull << (8 * code_bytes)) - 1)) return PQHIP_EINDEX_WIDTH;
     if (n > 0 && (x_rs < cb->d || o_rs < cb->M)) return PQHIP_ESHAPE;
     SET_DEVICE(cb->ctx->devs[slot]->ordinal);
-    return quantize_dev_impl(cb, slot, d_x, n, x_rs, d_codes, code_bytes, o_rs, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (code_bytes == 1 || code_bytes == 4) return quantize_dev_impl(cb, slot, d_x, n, x_rs, d_codes, code_bytes, o_rs, st);
+    if (n == 0) return PQHIP_OK;
+    const int dev_bytes = cb->K <= 256 ? 1 : 4;
+    const int M = (int)cb->M;
+    return with_converted_codes(cb, slot, n, st, dev_bytes, [&](void* tmp, int64_t r0, int64_t rows) -> int32_t {
+        PQCHK(quantize_dev_impl(cb, slot, d_x + r0 * x_rs, rows, x_rs, tmp, dev_bytes, M, st));
+        char* dst = (char*)d_codes + r0 * o_rs * code_bytes;
+        if (code_bytes == 2) return dev_bytes == 1 ? convert_codes<uint8_t, uint16_t>(tmp, M, dst, o_rs, rows, M, 0, nullptr, st)
+                                                   : convert_codes<uint32_t, uint16_t>(tmp, M, dst, o_rs, rows, M, 0, nullptr, st);
+        return dev_bytes == 1 ? convert_codes<uint8_t, uint64_t>(tmp, M, dst, o_rs, rows, M, 0, nullptr, st)
+                              : convert_codes<uint32_t, uint64_t>(tmp, M, dst, o_rs, rows, M, 0, nullptr, st);
+    });
 }
 
 int32_t pqhip_reconstruct_batch_f32_dev(pqhip_codebook* cb, int32_t slot, const void* d_codes,
@@ -296,11 +332,25 @@ int32_t pqhip_reconstruct_batch_f32_dev(pqhip_codebook* cb, int32_t slot, const 
     if (!cb || n < 0) return PQHIP_EINVAL;
     if (slot < 0 || slot >= (int)cb->dev.size()) return PQHIP_ENODEV;
     if (n > 0 && (!d_codes || !d_out)) return PQHIP_EINVAL;
-    if (code_bytes != 1 && code_bytes != 4) return PQHIP_EUNSUPPORTED;
+    if (code_bytes != 1 && code_bytes != 2 && code_bytes != 4 && code_bytes != 8) return PQHIP_EUNSUPPORTED;
     if (n > 0 && (c_rs < cb->M || o_rs < cb->d)) return PQHIP_ESHAPE;
     SET_DEVICE(cb->ctx->devs[slot]->ordinal);
-    return reconstruct_dev_impl(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs,
-                                (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (code_bytes == 1 || code_bytes == 4)
+        return reconstruct_dev_impl(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st);
+    if (n == 0) return PQHIP_OK;
+    const int M = (int)cb->M;
+    // (u32 scratch whatever K is: a 2- or 8-byte value >= K must raise the range flag, so it is clamped to K, which the
+    // gather then reports -- K itself does not fit a byte when K = 256)
+    return with_converted_codes(cb, slot, n, st, 4, [&](void* tmp, int64_t r0, int64_t rows) -> int32_t {
+        const char* src = (const char*)d_codes + r0 * c_rs * code_bytes;
+        {
+            ErrFlag ef(cb, slot, st);
+            if (code_bytes == 2) PQCHK((convert_codes<uint16_t, uint32_t>(src, c_rs, tmp, M, rows, M, (uint64_t)cb->K, ef.flag, st)));
+            else PQCHK((convert_codes<uint64_t, uint32_t>(src, c_rs, tmp, M, rows, M, (uint64_t)cb->K, ef.flag, st)));
+        }
+        return reconstruct_dev_impl(cb, slot, tmp, 4, rows, M, d_out + r0 * o_rs, o_rs, st);
+    });
 }
 
 int32_t pqhip_reconstruct_rows_f32_dev(pqhip_codebook* cb, int32_t slot, const void* d_codes,

@@ -4,6 +4,7 @@
 #include "pqhip_internal.h"
 
 #include "kernels_kmeans.hip.h"
+#include "kernels_atb.hip.h"
 
 using namespace pqhip;
 
@@ -213,32 +214,55 @@ static int32_t kmeans_run_dev(pqhip_codebook* cb, int slot, const float* d_x, in
     return PQHIP_OK;
 }
 
-// C[da][db] (device, row stride pb floats, padded to multiples of 64) = A^T . B over n rows with
-// rule-2 arithmetic (k_atb_blocks / k_atb_fold).  Row blocks are processed in groups whose partial
-// matrices fit 256 MiB; the fold carries C from group to group, so the block order is the row order.
-static int32_t atb_dev(DeviceSlot& ds, const float* dA, int64_t a_rs, int da, const float* dB, int64_t b_rs, int db, int64_t n,
-                float* dC, int pa, int pb, hipStream_t st)
+// C[da][db] (device, row stride pb = round_up(db, 16) floats, pa = round_up(da, 16) rows) = A^T . B over n rows with
+// rule-2 arithmetic (kernels_atb.hip.h: one workgroup per row block computes all of its output, k_atb_fold adds the
+// partial matrices in block order).  ga != nullptr: the rows of B are gathered from the codebook inside the kernel.
+// Parts are processed in groups whose partial matrices fit 4 GiB of workspace; the fold carries C from group to group,
+// so the order of the adds is the row order.  Context option "cross_product_exact" = 0: a part is 1/512 of the rows
+// instead of one 256-row block (float-tolerance mode; see the kernel's header).
+struct AtbGather { const void* codes; int64_t c_rs; int code_bytes; const float* cb; int K, dsub; };
+static int32_t atb_dev(pqhip_ctx* ctx, DeviceSlot& ds, const float* dA, int64_t a_rs, int da, const float* dB, int64_t b_rs, int db,
+                       const AtbGather* ga, int64_t n, float* dC, int pa, int pb, hipStream_t st)
 {
     if (n == 0) {
         HIPCHK(hipMemsetAsync(dC, 0, (size_t)pa * pb * sizeof(float), st));
         return PQHIP_OK;
     }
-    const int ti = pa / 64, tj = pb / 64;
+    const bool exact = ctx->opt.cross_product_exact.load(std::memory_order_relaxed) != 0;
     const int64_t total_blocks = (n + kKC - 1) / kKC;
+    // float-tolerance mode: ~2 parts per CU, whole 256-row blocks each
+    const int64_t blocks_per_part = exact ? 1 : std::max<int64_t>(1, (total_blocks + 2 * ds.n_cus - 1) / (2 * ds.n_cus));
+    const int64_t total_parts = (total_blocks + blocks_per_part - 1) / blocks_per_part;
     const int64_t per = (int64_t)pa * pb * sizeof(float);
-    int64_t G = std::max<int64_t>(4, ((256ll << 20) / per) & ~3ll);
-    G = std::min<int64_t>(G, round_up(total_blocks, 4));
+    const int64_t group_opt = ctx->opt.cross_product_group_bytes.load(std::memory_order_relaxed);
+    int64_t G = std::max<int64_t>(1, (group_opt > 0 ? group_opt : (4ll << 30)) / per);
+    G = std::min<int64_t>(G, total_parts);
     PQCHK(ensure_ws(ds, 2, (size_t)G * per));
     float* part = (float*)ds.ws[2];
-    for (int64_t g0 = 0; g0 < total_blocks; g0 += G) {
-        const int nb = (int)std::min<int64_t>(G, total_blocks - g0);
-        const unsigned grid = (unsigned)(((nb + 3) / 4) * ti * tj);
-        hipLaunchKernelGGL(k_atb_blocks, dim3(grid), dim3(256), 0, st, dA, a_rs, da, dB, b_rs, db, n, g0, nb, ti, tj,
-                           pa, pb, part);
+    AtbArgs a;
+    a.A = dA; a.a_rs = a_rs; a.da = da; a.B = dB; a.b_rs = b_rs; a.db = db;
+    a.codes = nullptr; a.c_rs = 0; a.cb = nullptr; a.K = 0; a.dsub = 1; a.inv_dsub = 0;
+    const bool gather = ga != nullptr;
+    if (gather) {
+        a.codes = ga->codes; a.c_rs = ga->c_rs; a.cb = ga->cb; a.K = ga->K; a.dsub = ga->dsub;
+        a.inv_dsub = (unsigned)(((1ull << 32) + ga->dsub - 1) / ga->dsub);
+    }
+    a.n = n; a.rows_per_part = blocks_per_part * kKC;
+    a.nba = (da + kAtbW - 1) / kAtbW; a.nbb = (db + kAtbW - 1) / kAtbW;
+    a.pa = pa; a.pb = pb; a.part = part;
+    if (pa * (int64_t)pb > (1ll << 31) || n >= (1ll << 40)) return PQHIP_EUNSUPPORTED;
+    // the padded rows / columns of C are never written by the kernel (only real 16 x 16 tiles are): keep them defined
+    for (int64_t g0 = 0; g0 < total_parts; g0 += G) {
+        const int np = (int)std::min<int64_t>(G, total_parts - g0);
+        a.row0 = g0 * a.rows_per_part; a.nparts = np;
+        const dim3 grid((unsigned)((int64_t)np * a.nba * a.nbb));
+        if (!gather) hipLaunchKernelGGL((k_atb_rowblock<false, uint8_t>), grid, dim3(512), 0, st, a);
+        else if (ga->code_bytes == 1) hipLaunchKernelGGL((k_atb_rowblock<true, uint8_t>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_atb_rowblock<true, uint32_t>), grid, dim3(512), 0, st, a);
         hipLaunchKernelGGL(k_atb_fold, dim3((unsigned)(((int64_t)pa * pb + 255) / 256)), dim3(256), 0, st,
-                           (const float*)part, nb, pa, pb, g0 == 0 ? 1 : 0, dC);
+                           (const float*)part, np, (int64_t)pa * pb, g0 == 0 ? 1 : 0, dC);
         HIPCHK(hipGetLastError());
-        note_kernel("k_atb_blocks");
+        note_kernel(gather ? "k_atb_rowblock<gather>" : "k_atb_rowblock");
         note_kernel("k_atb_fold");
     }
     return PQHIP_OK;
@@ -298,7 +322,7 @@ int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx* ctx, int32_t slot, float* quanti
     CodebookDev& cd = cb->dev[slot];
     hipStream_t st = (hipStream_t)stream;
     const int code_bytes = K <= 256 ? 1 : 4;
-    const int pa = (int)round_up(d, 64);
+    const int pa = (int)round_up(d, 16);
     DeviceSlot& ds = *ctx->devs[slot];
     std::lock_guard<std::mutex> tg(ds.train_mu);
     PQCHK(ensure_ws(ds, 0, (size_t)std::max<int64_t>(n, 1) * d * sizeof(float)));
@@ -310,14 +334,21 @@ int32_t pqhip_opq_train_step_f32_dev(pqhip_ctx* ctx, int32_t slot, float* quanti
     PQCHK(rotate_dev(d_x, n, x_rs, cd.P, (int)d, (float*)rx.p, d, st));
     // opq.rs:168  update_subquantizers: one kmeans_iteration per subquantizer on rx, loss discarded
     PQCHK(kmeans_run_dev(cb, slot, (const float*)rx.p, n, d, 1, nullptr, st));
-    // opq.rs:176-182  quantize -> reconstruct round trip with the new centroids (rx is recycled)
+    // opq.rs:176-182  quantize -> reconstruct round trip with the new centroids; opq.rs:191 instances.t().dot(&reconstructed).
+    // The reconstructed matrix is never written: the cross-product kernel gathers its rows from the codebook (sub-vectors
+    // of whole 16-byte pieces; other shapes reconstruct into rx first, which is recycled as in the reference).
     PQCHK(encode_plain_dev(cb, slot, (const float*)rx.p, n, d, codes.p, code_bytes, M, st));
-    {
-        ErrFlag ef(cb, slot, st);
-        PQCHK(gather_dev(cb, slot, codes.p, code_bytes, n, M, (float*)rx.p, d, st, ef.flag));
+    HIPCHK(hipMemsetAsync(dcross.p, 0, (size_t)pa * pa * sizeof(float), st));
+    if (dsub % 4 == 0) {
+        const AtbGather ga{codes.p, M, code_bytes, cd.cb, (int)K, (int)dsub};
+        PQCHK(atb_dev(ctx, ds, d_x, x_rs, (int)d, nullptr, 0, (int)d, &ga, n, (float*)dcross.p, pa, pa, st));
+    } else {
+        {
+            ErrFlag ef(cb, slot, st);
+            PQCHK(gather_dev(cb, slot, codes.p, code_bytes, n, M, (float*)rx.p, d, st, ef.flag));
+        }
+        PQCHK(atb_dev(ctx, ds, d_x, x_rs, (int)d, (const float*)rx.p, d, (int)d, nullptr, n, (float*)dcross.p, pa, pa, st));
     }
-    // opq.rs:191  instances.t().dot(&reconstructed)
-    PQCHK(atb_dev(ds, d_x, x_rs, (int)d, (const float*)rx.p, d, (int)d, n, (float*)dcross.p, pa, pa, st));
     HIPCHK(hipMemcpy2DAsync(cross, (size_t)d * sizeof(float), dcross.p, (size_t)pa * sizeof(float),
                             (size_t)d * sizeof(float), (size_t)d, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(quantizers, cd.cb, (size_t)(M * K * dsub) * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -333,12 +364,13 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx* ctx, int32_t slot, const float* d_a, i
     if (n > 0 && (!d_a || !d_b || a_rs < da || b_rs < db)) return PQHIP_EINVAL;
     SET_DEVICE(ctx->devs[slot]->ordinal);
     hipStream_t st = (hipStream_t)stream;
-    const int pa = (int)round_up(da, 64), pb = (int)round_up(db, 64);
+    const int pa = (int)round_up(da, 16), pb = (int)round_up(db, 16);
     DeviceSlot& ds = *ctx->devs[slot];
     std::lock_guard<std::mutex> tg(ds.train_mu);
     DevBuf dc;
     PQCHK(dc.alloc((size_t)pa * pb * sizeof(float)));
-    PQCHK(atb_dev(ds, d_a, a_rs, (int)da, d_b, b_rs, (int)db, n, (float*)dc.p, pa, pb, st));
+    HIPCHK(hipMemsetAsync(dc.p, 0, (size_t)pa * pb * sizeof(float), st));
+    PQCHK(atb_dev(ctx, ds, d_a, a_rs, (int)da, d_b, b_rs, (int)db, nullptr, n, (float*)dc.p, pa, pb, st));
     HIPCHK(hipMemcpy2DAsync(out, (size_t)db * sizeof(float), dc.p, (size_t)pb * sizeof(float),
                             (size_t)db * sizeof(float), (size_t)da, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -642,8 +642,10 @@ class Pq:
         if tuple(out.shape) != (x.shape[0], self.quantized_len()):
             raise PanicError("Quantized matrix has incorrect shape, expected: (%d, %d), got: (%d, %d)"
                              % (x.shape[0], self.quantized_len(), out.shape[0], out.shape[1]))
-        assert out.is_cuda and out.dtype in (torch.uint8, torch.int32) and out.stride(1) == 1
-        code_bytes = 1 if out.dtype == torch.uint8 else 4
+        # index type I of quantize_batch::<I, _>: uint8, or int16 / int32 / int64 tensors as 2- / 4- / 8-byte containers
+        # (u16 / u32 / u64 bit patterns)
+        assert out.is_cuda and out.dtype in (torch.uint8, torch.int16, torch.int32, torch.int64) and out.stride(1) == 1
+        code_bytes = out.element_size()
         cb = self._cb()
         if stream is None:
             stream = torch.cuda.current_stream(x.device).cuda_stream
@@ -659,12 +661,12 @@ class Pq:
         return out
 
     def reconstruct_batch_device(self, codes, out=None, stream=None, check=True):
-        """codes: CUDA uint8 tensor [n, M] -> float32 tensor [n, d].
+        """codes: CUDA uint8 (or int16 / int32 / int64 = u16 / u32 / u64 containers) tensor [n, M] -> float32 tensor [n, d].
         check=True (default) synchronises the stream and raises the reference's index panic
         (primitives.rs:146) when a code >= K was met; check=False leaves the call asynchronous and the
         violation pending on the stream's flag (a later check=True call on that stream reports it)."""
         import torch
-        assert codes.is_cuda and codes.dtype == torch.uint8 and codes.dim() == 2
+        assert codes.is_cuda and codes.dtype in (torch.uint8, torch.int16, torch.int32, torch.int64) and codes.dim() == 2
         if codes.shape[1] != self.quantized_len():
             raise PanicError("Quantization length does not match number of subquantizers")
         if codes.stride(1) != 1:
@@ -681,7 +683,7 @@ class Pq:
             stream = torch.cuda.current_stream(codes.device).cuda_stream
         slot = self._slot_for(codes)
         rc = _lib.lib().pqhip_reconstruct_batch_f32_dev(
-            cb, slot, codes.data_ptr(), 1, codes.shape[0],
+            cb, slot, codes.data_ptr(), codes.element_size(), codes.shape[0],
             codes.stride(0) if codes.shape[0] > 1 else max(codes.stride(0), codes.shape[1]),
             out.data_ptr(), out.stride(0) if out.shape[0] > 1 else max(out.stride(0), out.shape[1]),
             ctypes.c_void_p(stream))

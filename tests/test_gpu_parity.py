@@ -1064,22 +1064,48 @@ def test_opq_train_step_matches_oracle(ra, shape):
     assert got_q2.tobytes() == want_q.tobytes() and got_cross2.tobytes() == want_cross.tobytes()
 
 
-def test_at_dot_b_row_blocks_and_groups(ra):
-    """`a.t().dot(&b)`: chains restart every 256 rows, block results are added in row order --
-    across the 256 MiB partial-matrix groups too (300 x 300 outputs: 640 blocks per group)."""
+def test_at_dot_b_row_blocks_and_groups(ra, ctx_options):
+    """`a.t().dot(&b)`: chains restart every 256 rows, block results are added in row order -- across the launch groups of
+    partial matrices too (shrunk to 64 MiB here: 181 row blocks of a 300 x 300 output per group).  Outputs wider than one
+    workgroup's 320 x 320 (several output blocks), ragged last tiles, unaligned rows."""
     import torch
-    for (n, da, db) in [(1, 3, 5), (255, 7, 7), (256, 64, 65), (257, 20, 300), (3000, 130, 40)]:
+    for (n, da, db) in [(1, 3, 5), (255, 7, 7), (256, 64, 65), (257, 20, 300), (3000, 130, 40), (600, 700, 330), (513, 321, 17)]:
         a = synth.normalish(1700 + n, (n, da))
         b = synth.normalish(1701 + n, (n, db))
         got = ra.at_dot_b(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
         assert got.tobytes() == orc.at_dot_b(a, b, n_threads=8).tobytes(), (n, da, db)
-    n = 256 * 700 + 11                                     # two groups of row blocks at d = 300
+    ctx_options("cross_product_group_bytes", 64 << 20)
+    n = 256 * 700 + 11                                     # four groups of row blocks at d = 300
     g = torch.Generator(device="cuda").manual_seed(5)
     a = torch.randn((n, 300), device="cuda", generator=g)
     b = torch.randn((n, 300), device="cuda", generator=g)
+    ra.launch_log(reset=True)
     got = ra.at_dot_b(a, b)
-    want = orc.at_dot_b(a.cpu().numpy(), b.cpu().numpy(), n_threads=os.cpu_count() or 8)
+    assert ra.launch_log(reset=True) == "k_atb_rowblock x4 + k_atb_fold x4"
+    want = orc.at_dot_b(a.cpu().numpy(), b.cpu().numpy(), n_threads=min(os.cpu_count() or 8, 16))
     assert got.tobytes() == want.tobytes()
+    # float-tolerance mode: a plain split-K product (parts of many 256-row blocks), within north_star's 1e-5 relative
+    ctx_options("cross_product_exact", 0)
+    fast = ra.at_dot_b(a, b)
+    assert np.abs(fast - want).max() <= REL_TOL * np.abs(want).max()
+    assert fast.tobytes() != want.tobytes()                # (it IS another summation order)
+
+
+def test_opq_train_step_gathers_the_reconstruction_inside_the_cross_product(ra):
+    """opq.rs:176-191 without the reconstructed matrix in memory: for sub-vectors of whole 16-byte pieces the cross-product
+    kernel assembles the rows of R from the codebook; other sub-vectors reconstruct first.  Same bits either way (the
+    oracle reconstructs, then multiplies)."""
+    import torch
+    for (n, M, K, dsub, gathered) in [(3000, 15, 256, 20, True), (1500, 3, 300, 8, True), (1200, 5, 16, 6, False)]:
+        d = M * dsub
+        q0, x = _km_inputs(n, M, K, dsub, 1650 + n)
+        P = synth.orthonormal(1651 + n, d)
+        want_q, want_cross = orc.opq_train_step(q0, P, x, n_threads=8)
+        ra.launch_log(reset=True)
+        got_q, got_cross = ra.opq_train_step(q0, P, torch.from_numpy(x).cuda())
+        log = ra.launch_log(reset=True)
+        assert ("k_atb_rowblock<gather>" in log) == gathered and ("k_reconstruct" in log) == (not gathered), log
+        assert got_q.tobytes() == want_q.tobytes() and got_cross.tobytes() == want_cross.tobytes()
 
 
 def test_train_opq_statistical_loss(ra, kats):
