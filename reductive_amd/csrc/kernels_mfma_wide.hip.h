@@ -1,4 +1,5 @@
-// kernels_mfma_wide.hip.h -- PQ encode for sub-vectors of 129 .. 256 floats (d = 768 with M = 4, d = 1024 with M = 4 ...,
+// kernels_mfma_wide.hip.h -- PQ encode for sub-vectors of 129 .. 256 floats (k_encode_mfma_wide) and of 257 .. 1,024 floats
+// (k_encode_mfma_wide2, further down): sub-vectors of 129 .. 256 floats (d = 768 with M = 4, d = 1024 with M = 4 ...,
 // k-means over whole vectors of up to 256 dimensions): the shapes that still ran the scalar anchor kernel (4-16e5 vectors/s).
 //
 // One rule-2 chain is at most 256 k long, so these sub-vectors are still ONE fmaf chain per (row, centroid) -- up to 128
@@ -145,6 +146,155 @@ __global__ __launch_bounds__(256, 1) void k_encode_mfma_wide(EncodeArgs a, const
         const bool valid = row0 + j < a.n;
         // exact path: a negative / non-finite minimum (a NaN's bits sort above every finite value only when positive), a huge
         // or non-finite norm
+        const bool odd_row = !(bd >= 0.f) || !(bd < __builtin_inff()) || !(xr < kBigNorm);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && odd_row);
+        const unsigned need = (unsigned)(bal | (bal >> 32));
+        if (h == 0 && valid && !((need >> j) & 1u)) {
+            const unsigned gidx = (unsigned)best + 32u * (unsigned)T * (unsigned)grp;
+            reinterpret_cast<unsigned long long*>(a.out)[(row0 + j) * a.o_rs + m] = ((unsigned long long)ord_key(bd) << 32) | (unsigned long long)gidx;
+        }
+        if (need) encode_rows_slow_v<unsigned long long>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, a.groups, m, row0, need);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sub-vectors of 257 .. 1,024 floats (round 4; VERDICT r3 missing #3: these shapes still ran the scalar anchor kernel at
+// ~5e5 vectors/s).  A rule-2 dot product now spans NB = ceil(dsub / 256) chains: every 256-k block is its own fmaf chain from
+// +0 and the block results are added in block order with one rounded add each (C = fl(C + chain_b), matrixmultiply's KC loop).
+// Same plain structure as k_encode_mfma_wide, per 256-k block: the lane halves fetch their halves of the block's slice of the
+// sub-vector (the next (tile, block) slice travels from HBM while this block's chains run), one v_permlane32_swap per register
+// pair makes the B operands, T chains of up to 128 matrix instructions run against the fragments in LDS, and the block's
+// accumulators are added to the running dot products.  The fragments of ALL blocks stay in LDS ([T][DP / 2][64] floats:
+// T = 2 tiles = 64 centroids per group up to DP = 512, T = 1 beyond), so a group costs DP / 8 KB <= 128 KB.
+// DP = dsub padded to a multiple of 64 (zero k-padding is exact).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int T, int DP>
+__global__ __launch_bounds__(256, 1) void k_encode_mfma_wide2(EncodeArgs a, const float* __restrict__ xx)
+{
+    static_assert(T >= 1 && T <= 2 && DP % 64 == 0 && DP > 256 && DP <= 1024 && T * DP <= 1024, "no such instantiation");
+    constexpr int S = DP / 2;                 // matrix instructions per (row tile, centroid tile), all blocks
+    constexpr int NB = (DP + 255) / 256;      // rule-2 blocks
+    constexpr int WL = DP - 256 * (NB - 1);   // padded width of the last block (64 .. 256)
+    extern __shared__ __attribute__((aligned(16))) float wide_s[];
+    float* afrag_s = wide_s;                  // [T][S][64]
+    float* cc_s = wide_s + T * S * 64;        // [T * 32]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t q = b >> 3;
+    const int64_t g_local = q / a.M;
+    const int m = (int)(q - g_local * a.M);           // virtual subquantizer: (m_real, group)
+    const int64_t group = g_local * 8 + xcd;
+    const bool wg_active = (g_local < a.chunks_per_xcd) && (group < a.n_chunks);
+    if (wg_active) {
+        const float* fp = a.frags + (int64_t)m * T * S * 64;
+        for (int i = threadIdx.x; i < T * S * 64; i += 256) afrag_s[i] = fp[i];
+        const float* ccm = a.cc + (int64_t)m * T * 32;
+        for (int i = threadIdx.x; i < T * 32; i += 256) cc_s[i] = ccm[i];
+    }
+    __syncthreads();
+    const int64_t row_begin = (group * 4 + wave) * a.rows_per_item;
+    if (!wg_active || row_begin >= a.n) return;
+    int64_t row_end = row_begin + a.rows_per_item;
+    if (row_end > a.n) row_end = a.n;
+    const int m_real = m / a.groups, grp = m - m_real * a.groups;
+    const int Mreal = a.M / a.groups;
+    const float* xsub = a.x + (int64_t)m_real * a.dsub;
+
+    int lo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lo[r] = (r & 3) + 8 * (r >> 2) + 4 * h;       // centroid of accumulator register r inside a tile
+
+    // slice (tile, block kb) of width W: half h holds the floats [256 kb + h W / 2, + W / 2) of its row's sub-vector
+    float v[128];
+    auto fetch_slice = [&](int64_t tile_row0, int kb, int W) {
+        const int64_t row = (tile_row0 + j < a.n) ? tile_row0 + j : a.n - 1;    // rows past the end: clamped, never stored
+        const int base = 256 * kb + h * (W / 2);
+        int cnt = a.dsub - base;
+        cnt = cnt < 0 ? 0 : (cnt > W / 2 ? W / 2 : cnt);
+        load_row_floats_rt<128>(xsub + row * a.x_rs + base, cnt, v);
+    };
+    fetch_slice(row_begin, 0, 256);
+    for (int64_t row0 = row_begin; row0 < row_end; row0 += 32) {
+        const int64_t row_c = (row0 + j < a.n) ? row0 + j : a.n - 1;
+        const float xr = xx[row_c * Mreal + m_real];
+        f32x16 dp[T];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            constexpr int kFull = 256;
+            const int W = (kb == NB - 1) ? WL : kFull;                           // compile-time after unrolling
+            float bop[128];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                if (i < W / 4) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * i]), __float_as_uint(v[2 * i + 1]), false, false);
+                    bop[i] = __uint_as_float(r[0]);             // half 0: x[2i],       half 1: x[2i + 1]      (of the block)
+                    bop[W / 4 + i] = __uint_as_float(r[1]);     // half 0: x[W/2 + 2i], half 1: x[W/2 + 2i + 1]
+                }
+            }
+            {   // the next slice: the next block of this tile, or block 0 of the next tile (last tile: its own rows again, unused)
+                const bool last_blk = kb == NB - 1;
+                const int64_t nr0 = last_blk ? ((row0 + 32 < row_end) ? row0 + 32 : row0) : row0;
+                const int nkb = last_blk ? 0 : kb + 1;
+                fetch_slice(nr0, nkb, (nkb == NB - 1) ? WL : kFull);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const float* af = afrag_s + (t * S + 128 * kb) * 64 + lane;
+                constexpr int PF = 8;     // fragments requested PF matrix instructions ahead of their use (one wave per SIMD)
+                float fr[PF];
+#pragma unroll
+                for (int i = 0; i < PF; ++i) fr[i] = af[i * 64];
+#pragma unroll
+                for (int s2 = 0; s2 < 128; ++s2) {
+                    if (s2 < W / 2) {
+                        const float fa = fr[s2 % PF];
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s2 + PF < W / 2) fr[s2 % PF] = af[(s2 + PF) * 64];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, bop[s2], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (kb == 0) dp[t] = acc;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dp[t][e] = fadd(dp[t][e], acc[e]);   // rule 2: C = fl(C + chain_b)
+                }
+            }
+        }
+        const f32x2 xx2 = {xr, xr};
+        long long best = 0x7fffffffffffffffll;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(&cc_s[32 * t + 8 * g + 4 * h]);
+                const f32x2 c01 = {c4[0], c4[1]}, c23 = {c4[2], c4[3]};
+                f32x2 t01, t23;
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t01) : "v"(xx2), "v"(c01));
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t23) : "v"(xx2), "v"(c23));
+                const float tt[4] = {t01[0], t01[1], t23[0], t23[1]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = ffma(dp[t][4 * g + e], -2.0f, tt[e]);
+                    const long long key = ((long long)__float_as_int(d) << 32) | (long long)(unsigned)(32 * t + lo[4 * g + e]);
+                    best = key < best ? key : best;          // signed order of {bits(d), index} = (distance, index) for d >= 0
+                }
+            }
+        }
+        {   // the other half's candidate (centroids +4..7 of every group of 8), lower key wins
+            const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)(best >> 32), (unsigned)(best >> 32), false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)best, (unsigned)best, false, false);
+            const long long other = ((long long)(int)(h ? s0[0] : s0[1]) << 32) | (long long)(h ? s1[0] : s1[1]);
+            best = other < best ? other : best;
+        }
+        const float bd = __int_as_float((int)(best >> 32));
+        const bool valid = row0 + j < a.n;
         const bool odd_row = !(bd >= 0.f) || !(bd < __builtin_inff()) || !(xr < kBigNorm);
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(valid && odd_row);
         const unsigned need = (unsigned)(bal | (bal >> 32));

@@ -247,6 +247,14 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
         groups = (int)((K + 32 * T - 1) / (32 * T));
         cb->wide = true;
     }
+    if (K <= 65536 && dsub > 256 && dsub <= 1024) {
+        // several rule-2 blocks per dot product (k_encode_mfma_wide2): the fragments of all blocks of a group stay in LDS,
+        // T DP / 8 KB <= 128 KB -> groups of 64 centroids up to 512 floats, of 32 beyond
+        DP = (int)round_up(dsub, 64);
+        T = (DP <= 512 && K > 32) ? 2 : 1;
+        groups = (int)((K + 32 * T - 1) / (32 * T));
+        cb->wide = true;
+    }
     cb->T = T; cb->DP = DP; cb->groups = groups;
     cb->KP = (T != 0 && smallk_has((int)dsub)) ? smallk_kp(K) : 0;
     {   // pair kernel: K <= 16, power-of-two sub-vectors up to 16 floats, fragment image + slabs within 160 KB of LDS

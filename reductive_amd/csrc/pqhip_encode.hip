@@ -51,7 +51,7 @@ static int32_t encode_grouped_dev(pqhip_codebook* cb, int slot, const float* d_x
     return PQHIP_OK;
 }
 
-// 128 < dsub <= 256 (kernels_mfma_wide.hip.h): squared norms by a pre-pass, one 64-bit key per (row, group of <= 128
+// 128 < dsub <= 1,024 (kernels_mfma_wide.hip.h; beyond 256 floats the multi-block kernel k_encode_mfma_wide2): squared norms by a pre-pass, one 64-bit key per (row, group of <= 128
 // centroids) from the matrix-core kernel, k_merge_keys -> codes.  Keys and norms live in one leased scratch buffer, rows are
 // chunked so that it stays <= 1 GiB.
 static int32_t encode_wide_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t n, int64_t x_rs,

@@ -1,5 +1,6 @@
-// wide_launch.h -- host-side launcher of k_encode_mfma_wide (sub-vectors of 129 .. 256 floats); its 24 instantiations
-// (T in {1, 2, 4} x DP in {144, 160, .., 256}) live in their own translation unit, wide_launch.hip.
+// wide_launch.h -- host-side launcher of k_encode_mfma_wide (sub-vectors of 129 .. 256 floats: T in {1, 2, 4} x DP in
+// {144, 160, .., 256}) and of k_encode_mfma_wide2 (257 .. 1,024 floats: DP in {320, 384, .., 1024}, T = 2 up to 512, 1 beyond);
+// the instantiations live in their own translation unit, wide_launch.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels_mfma.hip.h"

@@ -30,8 +30,34 @@ static bool launch_t(int DP, const EncodeArgs& a, const float* xx, dim3 grid, hi
     }
 }
 
+template <int T, int DP>
+static bool launch_two(const EncodeArgs& a, const float* xx, dim3 grid, hipStream_t st)
+{
+    const size_t lds = ((size_t)T * (DP / 2) * 64 + (size_t)T * 32) * sizeof(float);
+    if (hipFuncSetAttribute((const void*)k_encode_mfma_wide2<T, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    hipLaunchKernelGGL((k_encode_mfma_wide2<T, DP>), grid, dim3(256), lds, st, a, xx);
+    return true;
+}
+
 bool launch_encode_wide(int T, int DP, const EncodeArgs& a, const float* xx, dim3 grid, hipStream_t st)
 {
+    if (DP > 256) {   // several rule-2 blocks per dot product: T = 2 up to 512 floats, T = 1 beyond (wide_geometry)
+        switch (DP) {
+        case 320: return T == 2 ? launch_two<2, 320>(a, xx, grid, st) : launch_two<1, 320>(a, xx, grid, st);
+        case 384: return T == 2 ? launch_two<2, 384>(a, xx, grid, st) : launch_two<1, 384>(a, xx, grid, st);
+        case 448: return T == 2 ? launch_two<2, 448>(a, xx, grid, st) : launch_two<1, 448>(a, xx, grid, st);
+        case 512: return T == 2 ? launch_two<2, 512>(a, xx, grid, st) : launch_two<1, 512>(a, xx, grid, st);
+        case 576: return T == 1 && launch_two<1, 576>(a, xx, grid, st);
+        case 640: return T == 1 && launch_two<1, 640>(a, xx, grid, st);
+        case 704: return T == 1 && launch_two<1, 704>(a, xx, grid, st);
+        case 768: return T == 1 && launch_two<1, 768>(a, xx, grid, st);
+        case 832: return T == 1 && launch_two<1, 832>(a, xx, grid, st);
+        case 896: return T == 1 && launch_two<1, 896>(a, xx, grid, st);
+        case 960: return T == 1 && launch_two<1, 960>(a, xx, grid, st);
+        case 1024: return T == 1 && launch_two<1, 1024>(a, xx, grid, st);
+        default: return false;
+        }
+    }
     switch (T) {
     case 1: return launch_t<1>(DP, a, xx, grid, st);
     case 2: return launch_t<2>(DP, a, xx, grid, st);

@@ -327,12 +327,14 @@ def test_more_than_256_centroids_on_the_matrix_path(ra, shape):
 
 
 @pytest.mark.parametrize("dsub", [33, 36, 40, 41, 47, 48, 50, 56, 57, 60, 63, 64, 65, 72, 80, 81, 96, 100, 112, 127, 128,
-                                  129, 144, 150, 176, 192, 200, 255, 256])
+                                  129, 144, 150, 176, 192, 200, 255, 256,
+                                  257, 300, 320, 321, 400, 512, 513, 600, 767, 768, 1000, 1024, 1025])
 def test_wide_subvectors_on_the_matrix_path(ra, dsub):
     """32 < dsub <= 128: the default kernel with one wave per SIMD and 20..64-MFMA chains (DP = 40,
     48, 56, 64, 80, 96, 112, 128 with zero k-padding); 128 < dsub <= 256: k_encode_mfma_wide (groups of <= 128 centroids,
-    norms by a pre-pass, keys merged) -- codes equal the oracle's, K <= 256 and grouped K > 256,
-    special values included; the k-means step on top of it."""
+    norms by a pre-pass, keys merged); 256 < dsub <= 1,024: k_encode_mfma_wide2 (several rule-2 blocks per dot product:
+    every 256-k block its own chain, block results added in order; groups of 64 / 32 centroids); beyond: the scalar anchor
+    -- codes equal the oracle's, K <= 256 and grouped K > 256, special values included; the k-means step on top of it."""
     for (n, M, K) in [(777, 3, 256), (300, 2, 37), (500, 2, 300)]:
         q = synth.normalish(1400 + dsub + K, (M, K, dsub))
         x = synth.normalish(1401 + dsub + K, (n, M * dsub))
@@ -343,7 +345,8 @@ def test_wide_subvectors_on_the_matrix_path(ra, dsub):
         want = orc.quantize_batch(q, x, dtype=dt)
         pq = _pq(ra, q)
         assert pq.quantize_batch(x, dtype=dt).tobytes() == want.tobytes(), (n, M, K)
-        assert pq.last_encode_kernel().startswith(("k_encode_mfma_lds3", "k_encode_mfma16") if dsub <= 128 else "k_encode_mfma_wide")
+        assert pq.last_encode_kernel().startswith(("k_encode_mfma_lds3", "k_encode_mfma16") if dsub <= 128 else
+                                                  "k_encode_mfma_wide" if dsub <= 1024 else "k_encode_scalar")
         rec = pq.reconstruct_batch(want)
         assert rec.tobytes() == orc.reconstruct_batch(q, want).tobytes()
     q0, xs = _km_inputs(1200, 2, 16, dsub, 1500 + dsub)
