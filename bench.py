@@ -506,8 +506,13 @@ def in_process(args, d, m, k, rows):
     rng = np.random.default_rng(42)
     x = rng.standard_normal((rows, d), dtype=np.float32)
     out = np.empty((rows, m), np.uint8 if k <= 256 else np.uint32)
+    # warm-up on the WHOLE batch: the pinned staging buffers of a device slot grow with the shard they serve, and a warm-up on
+    # 262,144 rows (rounds 2-3) sized them for 131 k-row shards when two slots shared the batch -- the first timed step then
+    # paid four 256 MB hipHostMalloc calls (50-60 ms, varying from box to box): the "two slots are slower than one" of
+    # VERDICT r3 weak #14 was this, not the link (gpurun_out/r4e/sweep.jsonl: a constant +41..59 ms per call at 2 M, 8 M and
+    # 16 M rows; tools/mb_h2d_concurrent.py: 56.5 GB/s aggregate for 1, 2 and 4 concurrent H2D streams)
     for _ in range(max(1, args.warmup)):
-        pq.quantize_batch_into(x[:min(rows, 262144)], out[:min(rows, 262144)])
+        pq.quantize_batch_into(x, out)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pq.quantize_batch_into(x, out)

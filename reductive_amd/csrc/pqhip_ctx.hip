@@ -3,6 +3,7 @@
 #include "pqhip_internal.h"
 
 #include <cstdlib>
+#include <sched.h>
 
 namespace pqh {
 
@@ -107,13 +108,40 @@ void RowPool::worker()
     }
 }
 
-// host threads per device slot for packing / draining (PQHIP_PACK_THREADS overrides; the GPU boxes give a
-// process 16 cores per GPU)
+// CPU cores this process may actually use: the scheduler affinity and the cgroup CPU quota (v2 `cpu.max`, v1
+// `cpu.cfs_quota_us`), whichever is smaller -- NOT std::thread::hardware_concurrency(), which reports the host's logical
+// CPUs (256 on the GPU boxes, of which a one-GPU job is granted 16).
+static unsigned usable_cores()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    double quota = 0;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {};
+        double per = 0;
+        if (std::fscanf(f, "%63s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) quota = atof(q) / per;
+        std::fclose(f);
+    } else {
+        double q = 0, per = 0;
+        if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lf", &q) != 1) q = 0; std::fclose(g); }
+        if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lf", &per) != 1) per = 0; std::fclose(g); }
+        if (q > 0 && per > 0) quota = q / per;
+    }
+    if (quota >= 1.0) n = std::min<unsigned>(n, (unsigned)(quota + 0.5));
+    return std::max(1u, n);
+}
+
+// host threads per device slot for packing / draining: the usable cores shared out over the context's device slots, at
+// most 16 each (PQHIP_PACK_THREADS overrides the cap).  Round 3 divided the host's LOGICAL cpu count: two slots on a
+// 16-core quota ran 2 x 16 packing threads and were throttled -- the two-slot rehearsal slid from 0.78x to 0.59x of one
+// slot's rate from box to box while the host code did not change.
 int pack_threads(size_t n_devs)
 {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    static const unsigned cores = usable_cores();
     static const unsigned cap = [] { const char* e = getenv("PQHIP_PACK_THREADS"); return e ? (unsigned)std::max(1, atoi(e)) : 16u; }();
-    return (int)std::max<unsigned>(1, std::min<unsigned>(cap, hw / (unsigned)std::max<size_t>(1, n_devs)));
+    return (int)std::max<unsigned>(1, std::min<unsigned>(cap, cores / (unsigned)std::max<size_t>(1, n_devs)));
 }
 
 // ---- staging buffers, training workspaces ------------------------------------------------------------------------

@@ -23,6 +23,83 @@ static bool apply_test_options(pqhip_ctx* ctx)
     return pqhip_ctx_set_option(ctx, "no_such_option", 1) == PQHIP_EINVAL;
 }
 
+extern "C" int mock_hip_violations(void);
+extern "C" int mock_hip_selftest(void);
+extern "C" int mock_hip_registrations(void);
+
+// "devices" mode (MOCK_HIP_DEVICES=8; both sanitizer builds run it): the library's own row sharder over EIGHT device slots,
+// every allocation / stream / event of the mock tagged with its device -- a pointer, stream or event of
+// slot A used while the thread is on device B, or through a stream of B, fails the run.  Host-resident encode at d = 300 and
+// at d = 768 / M = 48 (the size of BASELINE configs[4]) with a ragged row count, OPQ through the scratch leases, every index
+// width, strided outputs, reconstruct with a range error in the LAST shard, device entry points on every slot from eight
+// threads at once, a k-means call on the last slot.  With PQHIP_HOST_ZERO_COPY=1 the registered input leg runs too.
+static int devices_mode()
+{
+    int32_t nd = 0;
+    CHECK(pqhip_device_count(&nd) == PQHIP_OK && nd == 8);
+    CHECK(mock_hip_selftest() == 5);                        // the mock does see cross-device misuse
+    pqhip_ctx* ctx = nullptr;
+    CHECK(pqhip_ctx_create(nullptr, 0, &ctx) == PQHIP_OK && pqhip_ctx_n_devices(ctx) == 8);
+    CHECK(apply_test_options(ctx));
+    struct Shape { int64_t M, K, dsub, n; bool opq; };
+    for (const Shape sh : {Shape{15, 256, 20, 400003, false}, Shape{48, 256, 16, 90001, false}, Shape{15, 256, 20, 70001, true}}) {
+        const int64_t M = sh.M, K = sh.K, dsub = sh.dsub, d = M * dsub, n = sh.n;
+        std::vector<float> q((size_t)(M * K * dsub), 0.25f), P;
+        if (sh.opq) { P.assign((size_t)(d * d), 0.f); for (int64_t i = 0; i < d; ++i) P[(size_t)(i * d + i)] = 1.f; }
+        pqhip_codebook* cb = nullptr;
+        CHECK(pqhip_codebook_create(ctx, q.data(), M, K, dsub, sh.opq ? P.data() : nullptr, &cb) == PQHIP_OK);
+        std::vector<float> x((size_t)(n * (d + 3)), 1.0f);                       // row stride d + 3
+        for (int bytes : {1, 2, 8}) {
+            std::vector<uint8_t> codes((size_t)(n * (M + 2) * bytes), 0xee);     // row stride M + 2 elements
+            CHECK(pqhip_quantize_batch_f32(cb, x.data(), n, d + 3, 1, codes.data(), bytes, M + 2, 1) == PQHIP_OK);
+            for (int64_t i = 0; i < n; i += 49999)
+                for (int b = 0; b < 2 * bytes; ++b) CHECK(codes[(size_t)((i * (M + 2) + M) * bytes + b)] == 0xee);   // gaps untouched
+        }
+        {   // reconstruct: 8-byte codes, strided output; then a code >= K in the last row = the last shard
+            std::vector<uint64_t> codes((size_t)(n * M), 0);
+            std::vector<float> out((size_t)(n * (d + 1)), -1.f);
+            CHECK(pqhip_reconstruct_batch_f32(cb, codes.data(), 8, n, M, 1, out.data(), d + 1, 1) == PQHIP_OK);
+            CHECK(out[(size_t)d] == -1.f && out[(size_t)((n - 1) * (d + 1) + d)] == -1.f);
+            codes[(size_t)((n - 1) * M + M - 1)] = (1ull << 32) + 1;             // (a valid index once truncated to 32 bits)
+            CHECK(pqhip_reconstruct_batch_f32(cb, codes.data(), 8, n, M, 1, out.data(), d + 1, 1) == PQHIP_ECODE_RANGE);
+        }
+        {   // device entry points of all eight slots at once (host vectors stand in for caller-owned device memory)
+            std::vector<std::thread> th;
+            std::vector<int32_t> rc(8, -1);
+            for (int t = 0; t < 8; ++t)
+                th.emplace_back([&, t] {
+                    const int64_t rows = 5000 + 1000 * t;
+                    std::vector<float> xs((size_t)(rows * d), 1.f), out((size_t)(rows * d));
+                    std::vector<uint16_t> c((size_t)(rows * M));
+                    int32_t r = pqhip_quantize_batch_f32_dev(cb, t, xs.data(), rows, d, c.data(), 2, M, nullptr);
+                    if (r == PQHIP_OK) r = pqhip_reconstruct_batch_f32_dev(cb, t, c.data(), 2, rows, M, out.data(), d, nullptr);
+                    if (r == PQHIP_OK) r = pqhip_check_codes_dev(cb, t, nullptr);
+                    rc[(size_t)t] = r;
+                });
+            for (auto& t : th) t.join();
+            for (int32_t r : rc) CHECK(r == PQHIP_OK);
+        }
+        pqhip_codebook_destroy(cb);
+    }
+    {   // training entry points on the LAST slot: workspaces, the second stream, the cross-product groups
+        const int64_t M = 15, K = 256, dsub = 20, d = M * dsub;
+        std::vector<float> q((size_t)(M * K * dsub), 0.25f), P((size_t)(d * d), 0.f), xs((size_t)(30000 * d), 0.5f), loss((size_t)M), cross((size_t)(d * d));
+        for (int64_t i = 0; i < d; ++i) P[(size_t)(i * d + i)] = 1.f;
+        pqhip_matrix* mx = nullptr;
+        CHECK(pqhip_matrix_upload_f32(ctx, 7, xs.data(), 30000, d, d, 1, &mx) == PQHIP_OK);
+        CHECK(pqhip_kmeans_iterations_f32_dev(ctx, 7, q.data(), M, K, dsub, pqhip_matrix_device_ptr(mx), 30000, d, 2, loss.data(), nullptr) == PQHIP_OK);
+        CHECK(pqhip_opq_train_step_f32_dev(ctx, 7, q.data(), M, K, dsub, P.data(), pqhip_matrix_device_ptr(mx), 30000, d, cross.data(), nullptr) == PQHIP_OK);
+        pqhip_matrix_destroy(mx);
+    }
+    pqhip_ctx_destroy(ctx);
+    if (const char* z = std::getenv("PQHIP_HOST_ZERO_COPY")) {
+        if (z[0] == '1') CHECK(mock_hip_registrations() > 20);       // the registered leg really ran (every third request is refused)
+    }
+    CHECK(mock_hip_violations() == 0);
+    std::printf("host logic under sanitizers (8 tagged devices): all checks passed\n");
+    return 0;
+}
+
 // "threads" mode (the ThreadSanitizer build runs only this): many host threads lease, grow and release the scratch
 // buffers of ONE OPQ codebook and ONE K > 256 codebook on both device slots at once, with sizes that force the pool to
 // grow and buffers to be reallocated while other threads hold leases (ScratchLease::ptr() used to read the
@@ -76,6 +153,7 @@ static int threads_mode()
     pqhip_codebook_destroy(wide);
     pqhip_codebook_destroy(opq);
     pqhip_ctx_destroy(ctx);
+    CHECK(mock_hip_violations() == 0);
     std::printf("host logic under sanitizers (threads): all checks passed\n");
     return 0;
 }
@@ -83,6 +161,7 @@ static int threads_mode()
 int main(int argc, char** argv)
 {
     if (argc > 1 && std::string(argv[1]) == "threads") return threads_mode();
+    if (argc > 1 && std::string(argv[1]) == "devices") return devices_mode();
     int32_t nd = 0;
     CHECK(pqhip_device_count(&nd) == PQHIP_OK && nd == 2);
     pqhip_ctx* ctx = nullptr;
@@ -169,6 +248,7 @@ int main(int argc, char** argv)
     pqhip_codebook_destroy(opq);
     pqhip_codebook_destroy(pq);
     pqhip_ctx_destroy(ctx);
+    CHECK(mock_hip_violations() == 0);
     std::printf("host logic under sanitizers: all checks passed\n");
     return 0;
 }

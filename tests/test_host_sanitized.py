@@ -32,6 +32,44 @@ def test_host_logic_under_asan_ubsan_with_mock_hip():
         assert "AddressSanitizer" not in out and "runtime error" not in out and "LeakSanitizer" not in out, out[-4000:]
 
 
+def _run_devices_mode(build_dir, env, what):
+    """the multi-device driver (8 mock devices, every object tagged with its device) twice: the packing path and the
+    registered zero-copy input leg"""
+    for extra in ({}, {"PQHIP_HOST_ZERO_COPY": "1"}):
+        run = subprocess.run([os.path.join(MOCK, build_dir, "san_driver"), "devices"], capture_output=True, text=True,
+                             env=dict(env, MOCK_HIP_DEVICES="8", **extra), timeout=1500)
+        out = run.stdout + run.stderr
+        assert run.returncode == 0, out[-4000:]
+        assert "(8 tagged devices): all checks passed" in out
+        assert "MOCK-HIP DEVICE MISMATCH" not in out and what not in out and "runtime error" not in out, out[-4000:]
+
+
+def test_sharder_over_eight_tagged_mock_devices_under_asan_ubsan():
+    """multi-GPU readiness without a node.  The library's row sharder over EIGHT device slots of the
+    mock runtime, which tags every allocation, stream and event with its device and fails the run when one is used under
+    another device (its self-test proves it sees five kinds of misuse first): d = 300 and d = 768 / M = 48, ragged row
+    counts, OPQ, every index width, a range error in the last shard, all slots' device entry points at once, training
+    entry points on slot 7 -- under AddressSanitizer + UBSan with leak detection."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    build = subprocess.run(["make", "-C", MOCK, "-s", "-j8"], capture_output=True, text=True, timeout=1500)
+    assert build.returncode == 0, build.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:halt_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    _run_devices_mode("build", env, "AddressSanitizer")
+
+
+def test_sharder_over_eight_tagged_mock_devices_under_tsan():
+    """... and under ThreadSanitizer: eight shard threads, eight packing pools, the leases of eight device slots."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    san = "-fsanitize=thread -fno-omit-frame-pointer"
+    build = subprocess.run(["make", "-C", MOCK, "-s", "-j8", "SAN=" + san, "B=build_tsan"], capture_output=True, text=True, timeout=1500)
+    assert build.returncode == 0, build.stderr[-3000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    _run_devices_mode("build_tsan", env, "ThreadSanitizer")
+
+
 def test_host_threads_under_tsan_with_mock_hip():
     """the scratch-lease pool, the per-stream flag table and the device-slot staging shared by many host
     threads, under ThreadSanitizer (same mock HIP runtime; only the driver's multi-thread section runs)."""
