@@ -295,7 +295,9 @@ int32_t pqhip_set_rotation_variant(int32_t variant);
  *   "adc_single_query"     1 = one scan pass per query (default 0: 8 / 4 queries share a pass)
  *   "cross_product_exact"  0 = X^T.R of the OPQ training step / pqhip_at_dot_b_f32_dev as a plain split-K product:
  *                          within 1e-5 relative of the exact rule-2 result, no per-block partial matrices (default 1)
- *   "cross_product_group_bytes"  workspace of partial matrices per launch group (0 = 4 GiB)                      */
+ *   "cross_product_group_bytes"  workspace of partial matrices per launch group (0 = 4 GiB)
+ *   "lookup_two_pass"      row lookups (pqhip_reconstruct_rows*): 0 = one kernel, 1 = select the code rows into a compact
+ *                          staging area first, 2 (default) = two passes when the resident matrix exceeds 256 MB         */
 int32_t pqhip_ctx_set_option(pqhip_ctx *ctx, const char *name, int64_t value);
 /* Launch log of the calling thread: every kernel the library launches is noted by name; pqhip_launch_log() renders
  * "k_a + k_b x3 + ..." (distinct names in first-launch order with counts; valid until the thread's next call of

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
             if (e < rows * M) {
                 const int r = e / M, mm = e - r * M;
                 int64_t src = row0 + r;
-                if (SEL) {
+                if (SEL && sel_rows) {           // (SEL without sel_rows: rows already selected, only the scales apply)
                     src = sel_rows[src];
                     if (src < 0 || src >= n_codes) { bad = true; src = 0; }
                 }
@@ -89,8 +89,11 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
             pre[i] = v;
         }
         if (SEL && sel_scales && (int)threadIdx.x < rows) {
-            int64_t src = sel_rows[row0 + threadIdx.x];
-            if (src < 0 || src >= n_codes) src = 0;
+            int64_t src = row0 + threadIdx.x;
+            if (sel_rows) {
+                src = sel_rows[src];
+                if (src < 0 || src >= n_codes) src = 0;
+            }
             pre_scale = sel_scales[src * s_rs];
         }
     };
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void k_reconstruct_any(const IdxT* __restrict_
         uint64_t code = (uint64_t)codes[src * c_rs + m];
         if (code >= (uint64_t)K) { bad = true; code = 0; }
         float v = cb[((int64_t)m * K + (int64_t)code) * dsub + e];
-        if (sel_rows && sel_scales) v = fmul(v, sel_scales[src * s_rs]);
+        if (sel_scales) v = fmul(v, sel_scales[src * s_rs]);
         out[row * o_rs + c] = v;
     }
     if (bad) atomicOr(err, 1);
@@ -223,6 +226,32 @@ __global__ __launch_bounds__(256) void k_scale_rows(float* __restrict__ out, int
         if (src < 0 || src >= n_codes) src = 0;
         out[row * o_rs + c] = fmul(out[row * o_rs + c], sel_scales[src * s_rs]);
     }
+}
+
+// First pass of a lookup into a LARGE resident matrix (gather_dev: code matrix beyond the Infinity Cache): the selected code
+// rows and scales are copied into compact arrays, the reconstruct kernel then runs over those like a plain batch.
+// Why two passes (profiles/r4_lookup_counters.json): with 100 M resident rows every lookup is a translation miss in the
+// vector L1's TLB (3.3 M UTCL1 misses per 10 M lookups against 7 k at 10 M resident rows; L2 hit rate and DRAM requests
+// unchanged), and a miss stalls that L1's in-order pipeline for ALL waves of the CU -- the kernel's own 12 GB store stream
+// included: mean L1 -> L2 read latency 227 -> 474 cycles, the launch 2.66 -> 4.2 ms.  In this kernel the misses stall nothing
+// but other lookups.  One thread per code element (a row's M elements on consecutive lanes; writes are contiguous).
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_select_code_rows(const IdxT* __restrict__ codes, int64_t c_rs, int64_t n_codes,
+                                                          const int64_t* __restrict__ sel_rows, int64_t n, int M,
+                                                          IdxT* __restrict__ out_codes, const float* __restrict__ sel_scales,
+                                                          int64_t s_rs, float* __restrict__ out_scales, int* __restrict__ err)
+{
+    const int64_t total = n * M;
+    bool bad = false;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / M;
+        const int m = (int)(idx - row * M);
+        int64_t src = sel_rows[row];
+        if (src < 0 || src >= n_codes) { bad = true; src = 0; }
+        out_codes[idx] = codes[src * c_rs + m];
+        if (m == 0 && sel_scales) out_scales[row] = sel_scales[src * s_rs];
+    }
+    if (bad && err) atomicOr(err, 1);
 }
 
 // Index-width conversion for the device entry points with 2- and 8-byte codes (the reference is generic over the index

@@ -20,15 +20,25 @@ namespace pqh {
 // Nothing that can block for long -- hipEventSynchronize on the old buffer's work, hipFree, a <= 4 GiB
 // hipMalloc -- runs under cb->mu: the buffer is first marked leased (nobody else can pick it), then resized
 // with the mutex released, so other callers of the codebook (and every release_scratch) keep moving.
+// Nested leases (a call that holds a buffer and needs another: OPQ rotation scratch -> K > 256 keys; converted codes ->
+// rotation scratch -> keys; lookup staging) take their buffers from SEPARATE partitions of the pool, one per nesting depth of
+// the calling thread: a holder of a depth-0 buffer only ever waits for depth-1 buffers, whose holders wait for nothing of
+// depth <= 1 -- so three callers that each hold one buffer and want a second cannot wait for each other in a circle (with one
+// shared partition of three they could).
+thread_local int g_lease_depth = 0;
+
 int32_t lease_scratch(pqhip_codebook* cb, int slot, size_t bytes, hipStream_t st, int* out_idx, void** out_p)
 {
     CodebookDev& cd = cb->dev[slot];
+    const int level = std::min(g_lease_depth, kScratchLevels - 1);
+    const int lo = level * kScratchPoolMax, hi = lo + kScratchPoolMax;
     std::unique_lock<std::mutex> lk(cb->mu);
     for (;;) {
-        int idle_fit = -1, idle_any = -1, busy_fit = -1, busy_any = -1;
-        for (int i = 0; i < (int)cd.pool.size(); ++i) {
+        int idle_fit = -1, idle_any = -1, busy_fit = -1, busy_any = -1, fresh = -1;
+        for (int i = lo; i < hi; ++i) {
             ScratchBuf& b = cd.pool[i];
             if (b.leased) continue;
+            if (!b.done) { if (fresh < 0) fresh = i; continue; }      // slot never used: its event is created on first lease
             const bool idle = hipEventQuery(b.done) == hipSuccess;
             (void)hipGetLastError();
             const bool fit = b.bytes >= bytes;
@@ -38,15 +48,12 @@ int32_t lease_scratch(pqhip_codebook* cb, int slot, size_t bytes, hipStream_t st
             if (!idle && busy_any < 0) busy_any = i;
         }
         int pick = idle_fit;
-        if (pick < 0 && (int)cd.pool.size() < kScratchPoolMax) {
-            ScratchBuf nb;
-            HIPCHK(hipEventCreateWithFlags(&nb.done, hipEventDisableTiming));
-            cd.pool.push_back(nb);   // empty: grown below (a never-recorded event counts as complete); capacity is
-                                     // reserved at codebook creation, so elements never move
-            pick = (int)cd.pool.size() - 1;
+        if (pick < 0 && fresh >= 0) {
+            HIPCHK(hipEventCreateWithFlags(&cd.pool[fresh].done, hipEventDisableTiming));   // (a never-recorded event counts as complete)
+            pick = fresh;
         }
         if (pick < 0) pick = idle_any >= 0 ? idle_any : busy_fit >= 0 ? busy_fit : busy_any;
-        if (pick < 0) {              // every buffer is leased to another host thread
+        if (pick < 0) {              // every buffer of this depth is leased to another host thread
             cb->cv.wait(lk);
             continue;
         }
@@ -68,7 +75,7 @@ int32_t lease_scratch(pqhip_codebook* cb, int slot, size_t bytes, hipStream_t st
                 if (freed) { b.p = nullptr; b.bytes = 0; }   // (otherwise the old allocation stays on record)
                 b.leased = false;
                 lk.unlock();
-                cb->cv.notify_one();
+                cb->cv.notify_all();
                 g_hip_err = std::string("lease_scratch: ") + hipGetErrorString(e);
                 (void)hipGetLastError();
                 return (e == hipErrorOutOfMemory) ? PQHIP_ENOMEM : PQHIP_EHIP;
@@ -81,13 +88,14 @@ int32_t lease_scratch(pqhip_codebook* cb, int slot, size_t bytes, hipStream_t st
         if (e != hipSuccess) {
             b.leased = false;
             lk.unlock();
-            cb->cv.notify_one();
+            cb->cv.notify_all();
             g_hip_err = std::string("hipStreamWaitEvent(scratch): ") + hipGetErrorString(e);
             (void)hipGetLastError();
             return PQHIP_EHIP;
         }
         *out_idx = pick;
         *out_p = b.p;
+        ++g_lease_depth;
         return PQHIP_OK;
     }
 }
@@ -100,7 +108,8 @@ void release_scratch(pqhip_codebook* cb, int slot, int idx, hipStream_t st)
         (void)hipEventRecord(cd.pool[idx].done, st);
         cd.pool[idx].leased = false;
     }
-    cb->cv.notify_one();
+    --g_lease_depth;
+    cb->cv.notify_all();             // (waiters of different depths share the condition variable)
 }
 
 // ---- error-flag slots --------------------------------------------------------------------------------------------
@@ -273,7 +282,7 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
     }
 
     cb->dev.resize(ctx->devs.size());
-    for (CodebookDev& cd : cb->dev) cd.pool.reserve(kScratchPoolMax);
+    for (CodebookDev& cd : cb->dev) cd.pool.resize((size_t)kScratchPoolMax * kScratchLevels);   // fixed size: elements never move
     bool norms_ok = true;
     for (size_t i = 0; i < ctx->devs.size(); ++i) {
         if (only_slot >= 0 && (int)i != only_slot) continue;

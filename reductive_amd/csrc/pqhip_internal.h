@@ -57,8 +57,9 @@ constexpr int64_t kStageRowsMin = 4096;
 constexpr int64_t kScratchBytesMax = 4ll << 30;   // upper bound of one leased scratch buffer; the OPQ paths take far less
                                                   // (opq_chunk_rows: ~1.2 M rows, whole rounds of the rotation grid)
 constexpr int kRotRowsPerWg = 12 * 32 * 12;       // P-block rotation kernels: 12 waves x 12 tiles of 32 rows per workgroup
-constexpr int kScratchPoolMax = 3;                // leased scratch buffers per (codebook, device): <= 12 GiB of the 288 GB HBM,
-                                                  // and only while that many callers are inside OPQ calls at once
+constexpr int kScratchPoolMax = 3;                // leased scratch buffers per (codebook, device) and nesting depth: <= 12 GiB of the
+                                                  // 288 GB HBM per depth, and only while that many callers are inside such calls at once
+constexpr int kScratchLevels = 3;                 // nesting depths of leases (converted codes -> rotation scratch -> K > 256 keys)
 constexpr int kErrSlots = 64;                     // per-stream "code >= K" flags per (codebook, device)
 constexpr int kTrainWs = 10;                      // grow-only training workspaces per device
 constexpr int kStageSets = 4;                     // staging sets per device slot (concurrent host callers on one device)
@@ -82,6 +83,7 @@ struct Options {
     std::atomic<int64_t> opq_gather_rotation{1};    // 0: OPQ reconstruct as gather -> scratch -> rotation
     std::atomic<int64_t> adc_single_query{0};       // 1: one scan pass per query
     std::atomic<int64_t> cross_product_exact{1};    // 0: X^T.R as a plain split-K product (float tolerance, no per-block partials)
+    std::atomic<int64_t> lookup_two_pass{2};        // row lookups: 0 one pass, 1 select-then-reconstruct, 2 two passes when the matrix exceeds 256 MB
     std::atomic<int64_t> cross_product_group_bytes{0};   // workspace of partial matrices per launch group (0: 4 GiB; tests shrink it)
 };
 
@@ -268,7 +270,7 @@ struct CodebookDev {
     std::vector<uint64_t> err_used;        // last use of slot i (err_clock ticks)
     std::vector<hipEvent_t> err_done;      // recorded on the slot's stream behind the last kernels that may raise the flag
     uint64_t err_clock = 0;
-    std::vector<ScratchBuf> pool;          // under cb->mu; capacity kScratchPoolMax reserved at creation (elements never move)
+    std::vector<ScratchBuf> pool;          // under cb->mu; kScratchPoolMax x kScratchLevels slots, sized at creation (elements never move)
 };
 
 }  // namespace pqh

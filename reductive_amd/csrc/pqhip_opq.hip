@@ -32,6 +32,10 @@ int resident_wgs(const void* kernel, size_t lds)
     return nb;
 }
 
+static int32_t gather_compact(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes, int64_t n, int64_t c_rs, float* d_out,
+                              int64_t o_rs, hipStream_t st, int* err, const float* sel_scales, const int64_t* sel_rows = nullptr,
+                              int64_t n_codes = 0, int64_t s_rs = 1);
+
 int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes, int64_t n,
                    int64_t c_rs, float* d_out, int64_t o_rs, hipStream_t st, int* err,
                    const int64_t* sel_rows, int64_t n_codes, const float* sel_scales, int64_t s_rs)
@@ -39,6 +43,51 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     if (n == 0) return PQHIP_OK;
     CodebookDev& cd = cb->dev[slot];
     const int d = (int)cb->d;
+    // Lookups into a resident matrix beyond the Infinity Cache (256 MB): two passes -- k_select_code_rows copies the selected
+    // code rows and scales into a leased compact staging area, then this function runs again over it as a plain batch (with
+    // per-row scales).  The random 15-byte reads miss the vector L1's TLB at that size, and a miss stalls the CU's whole
+    // memory pipeline, the 1.2 KB-per-row store stream included (counters in kernels_gather.hip.h / profiles/r4_lookup_counters.json):
+    // 100 M resident rows, 10 M lookups: 4.2 -> see DESIGN.md; +2.5 % bytes (the staging round trip).  Option "lookup_two_pass":
+    // 0 never, 1 always, default by size.
+    if (sel_rows) {
+        const int64_t opt = cb->ctx->opt.lookup_two_pass.load(std::memory_order_relaxed);
+        const bool big = (double)n_codes * (double)c_rs * code_bytes > 256.0 * 1024 * 1024;
+        if ((opt == 1 || (opt != 0 && big)) && (code_bytes == 1 || code_bytes == 4)) {
+            const int64_t M = cb->M;
+            const int64_t per_row = M * code_bytes + 4;
+            const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (1ll << 30) / per_row));
+            ScratchLease st_buf(cb, slot, st);
+            PQCHK(st_buf.acquire((size_t)chunk * per_row + 16));
+            float* sc = (float*)st_buf.ptr();                                  // [chunk] scales, then [chunk][M] codes (4-byte aligned)
+            void* cc = (void*)(sc + chunk);
+            for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+                const int64_t rows = std::min<int64_t>(chunk, n - r0);
+                const unsigned g = (unsigned)std::min<int64_t>((rows * M + 255) / 256, (int64_t)cus_of(cb, slot) * 64);
+                if (code_bytes == 1)
+                    hipLaunchKernelGGL((k_select_code_rows<uint8_t>), dim3(g), dim3(256), 0, st, (const uint8_t*)d_codes, c_rs, n_codes,
+                                       sel_rows + r0, rows, (int)M, (uint8_t*)cc, sel_scales, s_rs, sc, err);
+                else
+                    hipLaunchKernelGGL((k_select_code_rows<uint32_t>), dim3(g), dim3(256), 0, st, (const uint32_t*)d_codes, c_rs, n_codes,
+                                       sel_rows + r0, rows, (int)M, (uint32_t*)cc, sel_scales, s_rs, sc, err);
+                HIPCHK(hipGetLastError());
+                note_kernel("k_select_code_rows");
+                PQCHK(gather_compact(cb, slot, cc, code_bytes, rows, M, d_out + r0 * o_rs, o_rs, st, err, sel_scales ? sc : nullptr));
+            }
+            return PQHIP_OK;
+        }
+    }
+    return gather_compact(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st, err, sel_scales, sel_rows, n_codes, s_rs);
+}
+
+// the reconstruct launch proper.  sel_rows == nullptr with sel_scales != nullptr: rows already selected (compact staging of
+// the two-pass lookup), scale i belongs to row i.
+static int32_t gather_compact(pqhip_codebook* cb, int slot, const void* d_codes, int code_bytes, int64_t n, int64_t c_rs, float* d_out,
+                                   int64_t o_rs, hipStream_t st, int* err, const float* sel_scales, const int64_t* sel_rows, int64_t n_codes,
+                                   int64_t s_rs)
+{
+    CodebookDev& cd = cb->dev[slot];
+    const int d = (int)cb->d;
+    const bool sel = sel_rows != nullptr || sel_scales != nullptr;            // the SEL form of the kernel
     // 16-byte output chunks whenever a row is a whole number of them (the stores are dword-aligned
     // wide stores, so neither the row stride nor the base address matters); a chunk is filled with
     // one, two or four codebook accesses depending on how sub-vectors line up with it
@@ -85,14 +134,14 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     const int64_t nblocks = (n + rows_per_block - 1) / rows_per_block;
     const size_t lds = (((size_t)cpr * ((vec && gsz) ? 4 / gsz : 1) * sizeof(int) + 15) & ~(size_t)15) +
                        (((size_t)2 * rows_per_block * cb->M * code_bytes + 15) & ~(size_t)15) +
-                       (sel_rows ? (size_t)2 * rows_per_block * sizeof(float) : 0);
+                       (sel ? (size_t)2 * rows_per_block * sizeof(float) : 0);
 #define LAUNCH_REC3(IDX, V, GG, NEE)                                                              \
     do {                                                                                          \
         const int per_cu = rec_wgs_per_cu ? rec_wgs_per_cu                                        \
-            : sel_rows ? 3 * resident_wgs((const void*)k_reconstruct<IDX, V, true, GG, NEE>, lds) \
+            : sel ? 3 * resident_wgs((const void*)k_reconstruct<IDX, V, true, GG, NEE>, lds) \
                        : std::min(4, resident_wgs((const void*)k_reconstruct<IDX, V, false, GG, NEE>, lds)); \
         const unsigned grid = (unsigned)std::min<int64_t>(nblocks, (int64_t)cus_of(cb, slot) * per_cu); \
-        if (sel_rows)                                                                             \
+        if (sel)                                                                                  \
             hipLaunchKernelGGL((k_reconstruct<IDX, V, true, GG, NEE>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
                                (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
@@ -123,7 +172,7 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
 #undef LAUNCH_REC2
 #undef LAUNCH_REC
     HIPCHK(hipGetLastError());
-    note_kernel(sel_rows ? "k_reconstruct<lookup>" : "k_reconstruct");
+    note_kernel(sel_rows ? "k_reconstruct<lookup>" : sel ? "k_reconstruct<scaled>" : "k_reconstruct");
     return PQHIP_OK;
 }
 

@@ -22,7 +22,7 @@ def kats():
 
 _OPTION_DEFAULTS = {"kmeans_window_rows": 0, "kmeans_lane_form": 0, "kmeans_no_graph": 0, "opq_scratch_rows": 0,
                     "opq_fused": 1, "opq_gather_rotation": 1, "adc_single_query": 0, "cross_product_exact": 1,
-                    "cross_product_group_bytes": 0}
+                    "cross_product_group_bytes": 0, "lookup_two_pass": 2}
 
 
 @pytest.fixture

@@ -1004,8 +1004,12 @@ def test_train_pq_statistical_loss(ra, kats):
 # ---- "next" row 2: lookup path of a resident quantized matrix (select + reconstruct + rescale) ----
 @pytest.mark.parametrize("shape", [(5000, 15, 256, 20, False), (3000, 5, 40, 7, False), (2000, 8, 64, 8, True),
                                    (900, 3, 300, 6, False), (400, 4200, 2, 1, False)])
-def test_lookup_rows_matches_select_reconstruct_scale(ra, shape):
+@pytest.mark.parametrize("two_pass", [0, 1])
+def test_lookup_rows_matches_select_reconstruct_scale(ra, ctx_options, shape, two_pass):
+    """(two_pass: the one-kernel lookup, and the select-then-reconstruct form that large resident matrices take by default --
+    forced here through the context option "lookup_two_pass")"""
     import torch
+    ctx_options("lookup_two_pass", two_pass)
     N, M, K, dsub, opq = shape
     d = M * dsub
     q = synth.normalish(1100 + N, (M, K, dsub))
