@@ -291,7 +291,14 @@ class Bench:
             extra["encode_kernel"] = pq.last_encode_kernel()
 
         sec = kernel_ms * 1e-3
-        traffic_rec, why = load_pmc_traffic(workload, rows, d, m, k, "_q%d" % args.queries if (workload == "adc_scan" and args.queries > 1) else "")
+        suffix = ""
+        if workload == "adc_scan" and args.queries > 1:
+            suffix = "_q%d" % args.queries
+        if workload == "lookup" and args.lookup_codes != 10_000_000:
+            suffix = "_codes%d" % args.lookup_codes
+        if workload == "opq_train" and args.fast_cross:
+            suffix = "_fastcross"
+        traffic_rec, why = load_pmc_traffic(workload, rows, d, m, k, suffix)
         traffic = traffic_rec["hbm_bytes_per_launch"] if traffic_rec else None
         if workload in ("reconstruct", "lookup", "adc_scan"):
             if workload == "lookup":

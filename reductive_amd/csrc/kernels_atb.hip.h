@@ -81,6 +81,24 @@ __global__ __launch_bounds__(512, 1) void k_atb_rowblock(AtbArgs a)
         srow[i] = idx / 80;
         scol[i] = 4 * (idx - 80 * srow[i]);
     }
+    // GATHER: the codes of a slab are requested one slab BEFORE its codebook rows (code -> codebook row is a dependent chain
+    // of two memory round trips, and a slab lasts only ~2.8 us): cpre holds the codes of the slab that fetch() is about to use
+    unsigned cpre[NP] = {};
+    auto fetch_codes = [&](int64_t rs) {
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int64_t r = rs + srow[i];
+                const int c = scol[i];
+                unsigned code = 0;
+                if (srow[i] < kAtbSR && r < r_end && c < wb) {
+                    const unsigned m = __umulhi((unsigned)(cb0 + c), a.inv_dsub);
+                    code = (unsigned)reinterpret_cast<const IdxT*>(a.codes)[r * a.c_rs + m];
+                }
+                cpre[i] = code;
+            }
+        }
+    };
     auto fetch = [&](int64_t rs, f32x4 (&sa)[NP], f32x4 (&sb)[NP]) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -104,8 +122,7 @@ __global__ __launch_bounds__(512, 1) void k_atb_rowblock(AtbArgs a)
                         const unsigned col = (unsigned)(cb0 + c);
                         const unsigned m = __umulhi(col, a.inv_dsub);
                         const unsigned off = col - m * (unsigned)a.dsub;
-                        unsigned code = (unsigned)reinterpret_cast<const IdxT*>(a.codes)[r * a.c_rs + m];
-                        code = code < (unsigned)a.K ? code : 0u;
+                        const unsigned code = cpre[i] < (unsigned)a.K ? cpre[i] : 0u;
                         const float* br = a.cb + ((int64_t)m * a.K + code) * a.dsub + off;
                         if (c + 4 <= wb) qb = *reinterpret_cast<const f32x4_u*>(br);
                         else { for (int e = 0; e < 4; ++e) if (c + e < wb) qb[e] = br[e]; }
@@ -134,13 +151,18 @@ __global__ __launch_bounds__(512, 1) void k_atb_rowblock(AtbArgs a)
         for (int c = 0; c < kAtbNTC; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 sa[NP], sb[NP];
+    fetch_codes(r_begin);
     fetch(r_begin, sa, sb);
+    fetch_codes(r_begin + kAtbSR);
     stash(0, sa, sb);
     __syncthreads();
     int buf = 0;
     for (int64_t rs = r_begin; rs < r_end; rs += kAtbSR, buf ^= 1) {
         const bool more = rs + kAtbSR < r_end;                     // workgroup-uniform
-        if (more) fetch(rs + kAtbSR, sa, sb);                      // next slab in flight behind this slab's matrix instructions
+        if (more) {
+            fetch(rs + kAtbSR, sa, sb);                            // next slab in flight behind this slab's matrix instructions
+            fetch_codes(rs + 2 * kAtbSR);                          // (rows past the end of the part: guarded inside)
+        }
 #pragma unroll
         for (int g = 0; g < kAtbSR / 4; ++g) {
             const float* ra = &slab[buf][0][4 * g + q][16 * kAtbNT * wr + i16];

@@ -15,11 +15,13 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-WL=${*:-"encode opq_encode reconstruct reconstruct100 encode_d768 lookup adc_scan adc_scan8 opq_reconstruct kmeans opq_train smallk"}
+WL=${*:-"encode opq_encode reconstruct reconstruct100 encode_d768 lookup lookup100 adc_scan adc_scan8 opq_reconstruct kmeans opq_train opq_train_fast smallk"}
 for W in $WL; do
   case $W in
     reconstruct100) ARGS="--workload reconstruct --rows 100000000";;
     adc_scan8) ARGS="--workload adc_scan --queries 8";;
+    lookup100) ARGS="--workload lookup --lookup-codes 100000000";;
+    opq_train_fast) ARGS="--workload opq_train --fast-cross";;
     smallk) ARGS="--workload encode --d 128 --m 16 --k 16";;
     *) ARGS="--workload $W";;
   esac

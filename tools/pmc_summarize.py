@@ -95,10 +95,15 @@ for w in wls:
     c = b["config"]
     fetch_b = sum(f) / len(f) * 1024 * 2
     write_b = sum(wr) / len(wr) * 1024
-    wl_name = {"reconstruct100": "reconstruct", "adc_scan8": "adc_scan", "smallk": "encode"}.get(w, w)
+    wl_name = {"reconstruct100": "reconstruct", "adc_scan8": "adc_scan", "smallk": "encode", "lookup100": "lookup",
+               "opq_train_fast": "opq_train"}.get(w, w)
     key = "%s@%d@d%d_m%d_k%d" % (wl_name, c["rows_per_gpu"], c["d"], c["M"], c["K"])
     if b.get("queries_per_scan", 1) > 1:
         key += "_q%d" % b["queries_per_scan"]
+    if w == "lookup100":
+        key += "_codes100000000"
+    if w == "opq_train_fast":
+        key += "_fastcross"
     alg = b["roofline"].get("algorithmic_bytes_per_vector", 0) * c["rows_per_gpu"]
     entries[key] = {"workload": wl_name, "rows": c["rows_per_gpu"], "kernel": kern[:120], "calls_in_stats_pass": int(s["Calls"]),
                     "avg_launch_ms_stats_pass": float(s["AverageNs"]) / 1e6,
