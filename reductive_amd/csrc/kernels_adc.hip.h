@@ -1,7 +1,7 @@
 // kernels_adc.hip.h -- "next" row: asymmetric distance computation over a
 // resident code matrix.  Lookup tables from the reference's own vector-to-matrix distance
 // (linalg.rs:118-148), then a table-sum scan over the u8 codes -- HBM-bound: M bytes in, 4 bytes out
-// per code row.  (Non-template kernels: include from exactly one translation unit, pqhip.hip.)
+// per code row.  (Non-template kernels: include from exactly one translation unit, pqhip_adc.hip.)
 #pragma once
 #include "common.hip.h"
 

@@ -2,7 +2,7 @@
 // SURVEY.md section 8f rank 1): update_centroids (kmeans.rs:166-198) and mean_squared_error
 // (kmeans.rs:329-360) for all M subquantizers at once, bit-identical to the reference's
 // sequential f32 arithmetic.  The assignment step is the encode kernel itself.
-// Include from exactly one translation unit (pqhip.hip).
+// Include from exactly one translation unit (pqhip_train.hip).
 //
 // update_centroids adds the instances of a cluster IN ROW ORDER, so the sum of every (cluster,
 // dimension) is one sequential chain.  The chains are independent of one another: a stable

@@ -1,6 +1,6 @@
 // kernels_pair16.hip.h -- PQ encode for codebooks of K <= 16 centroids with sub-vectors of 2, 4, 8 or 16 floats
 // (the reference's own Criterion shape is d = 128, M = 16, K = 16: benches/pq.rs:9-10).  HBM-bound work: 4 d + M bytes per
-// vector against 2 K d = 4,096 flop.  (Included from exactly one translation unit, pqhip.hip.)
+// vector against 2 K d = 4,096 flop.  (Template kernel: instantiated from pqhip_encode.hip.)
 //
 // Why another kernel: per (row, subquantizer) there are only 16 distances, so what a kernel pays PER TILE decides.  The
 // default MFMA kernel spends a 32-centroid tile (half of it padding) and its whole row-tile seam on every subquantizer

@@ -1,11 +1,11 @@
 // kernels_rotate8.hip.h -- OPQ rotation GEMM, eighth version: P-block stationary, x rows straight from
 // global memory into the MFMA operand registers, operands swapped so that the result tile leaves the
-// accumulators as 16-byte row pieces.  (Non-template-instantiated in one TU only: pqhip.hip.)
+// accumulators as 16-byte row pieces.  (Template kernels: instantiated from pqhip_rotate.hip; the burst helpers are shared with kernels_opq_fused2.hip.h.)
 //
 //   out[n][c] = sum_k x[n][k] * Pm[k][c]   (pq.rs:276 with Pm = projection, pq.rs:324 with Pm = projection^T),
 //   rule-2 chains: one k-ordered fmaf chain per output element, restarted every 256 k, blocks added in order.
 //
-// What round 2's stamps said about v6 (k_rotate_pblock6): its k loop is 90 % matrix issue, but every 32-row
+// What round 2's stamps said about v6 (k_rotate_pblock6, removed from the library in round 4): its k loop is 90 % matrix issue, but every 32-row
 // tile ends in an 8.5 k-cycle MFMA-free epilogue (32 ds_write_b32 + 8 ds_read_b128 to transpose the tile for
 // 16-byte stores) and every 16-k slab of x goes global -> registers -> LDS -> registers with a vmcnt wait in
 // front of the LDS store that exposes the fetch (-14 % without it).  This version removes both LDS round trips:

@@ -185,8 +185,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         a.M = (int)cb->M; a.K = (int)cb->K; a.dsub = (int)cb->dsub; a.k_pad = cb->k_pad;
         a.groups = 1;
         a.bad_flag = bad_flag;
-        // kernel kind: 0 VALU argmin, 2 LDS argmin + LDS A fragments (variant 3, the retired
-        // register-resident LDS-argmin kernel, is an alias of the default)
+        // kernel kind: 0 VALU argmin, 2 LDS argmin + LDS A fragments, 3 the same epilogue on 16x16x4
         // auto: for sub-vectors of <= 2 floats the per-distance work outweighs the MFMA chain and the
         // LDS pipe (one atomic per 64 distances) becomes the bound: the VALU-argmin kernel is 4-20 % faster
         // (round 3: with the hybrid lane-local + LDS argmin of the default kernel, 4-float sub-vectors moved to the default:

@@ -293,7 +293,7 @@ struct pqhip_codebook {
     bool has_proj = false;
     // MFMA encode geometry (0 = shape not covered, anchor kernel is used)
     int T = 0, DP = 0, k_pad = 0;
-    bool wide = false;      // 128 < dsub <= 256: groups of 32 T <= 128 centroids through k_encode_mfma_wide (kernels_mfma_wide.hip.h)
+    bool wide = false;      // 128 < dsub <= 1,024: groups of 32 T <= 128 centroids through k_encode_mfma_wide / _wide2 (kernels_mfma_wide.hip.h)
     int KP = 0;             // small codebooks (K <= 64, instantiated dsub): padded centroid count of the VALU kernel
     bool pair16 = false;    // K <= 16 and dsub in {2, 4, 8, 16}: the two-subquantizers-per-tile kernel applies
     int groups = 1;         // K > 256: groups of 256 centroids (8 tiles each) merged through 64-bit keys

@@ -47,7 +47,7 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
     // code rows and scales into a leased compact staging area, then this function runs again over it as a plain batch (with
     // per-row scales).  The random 15-byte reads miss the vector L1's TLB at that size, and a miss stalls the CU's whole
     // memory pipeline, the 1.2 KB-per-row store stream included (counters in kernels_gather.hip.h / profiles/r4_lookup_counters.json):
-    // 100 M resident rows, 10 M lookups: 4.2 -> see DESIGN.md; +2.5 % bytes (the staging round trip).  Option "lookup_two_pass":
+    // 100 M resident rows, 10 M lookups: 4.2 -> 3.2 ms (0.37 -> 0.48 of HBM); +2.5 % bytes (the staging round trip).  Option "lookup_two_pass":
     // 0 never, 1 always, default by size.
     if (sel_rows) {
         const int64_t opt = cb->ctx->opt.lookup_two_pass.load(std::memory_order_relaxed);
@@ -95,7 +95,7 @@ static int32_t gather_compact(pqhip_codebook* cb, int slot, const void* d_codes,
     // (gsz 0, odd sub-vectors of >= 5 floats: one unaligned 16-byte access per chunk that lies inside a sub-vector,
     // element-wise across a boundary -- 10 M x 300: dsub 15 4.10 -> 3.50 ms, dsub 5 5.30 -> 4.59 ms; even sub-vectors keep
     // two aligned 8-byte accesses per chunk, which is faster there: dsub 30 2.15 vs 3.09 ms.
-    // PQHIP_DEBUG_REC_ELEMWISE=1: the per-element form, for A/B)
+    // diagnostic builds, PQHIP_DEBUG_REC_ELEMWISE=1: the per-element form, for A/B)
     const bool rec_elemwise = diag().rec_elemwise;
     const int gsz = !vec ? 1 : (cb->dsub % 4 == 0) ? 4 : (cb->dsub % 2 == 0) ? 2 : (cb->dsub > 4 && !rec_elemwise) ? 0 : 1;
     const int cpr = vec ? d / 4 : d;
@@ -129,7 +129,7 @@ static int32_t gather_compact(pqhip_codebook* cb, int slot, const void* d_codes,
     // write slower than 1024 (100 M rows: 22.3 vs 19.4 ms on one box; a store-only kernel shows the same trend).
     // The lookup form (random source rows: workgroup times vary, reads matter) takes three rounds of its resident
     // count in shorter ranges (2.55 ms per 10 M rows against 2.8-2.9 with 4 or 8 per CU).
-    // PQHIP_DEBUG_REC_WGS overrides the per-CU count.
+    // (Diagnostic builds: PQHIP_DEBUG_REC_WGS overrides the per-CU count.)
     const int rec_wgs_per_cu = diag().rec_wgs;
     const int64_t nblocks = (n + rows_per_block - 1) / rows_per_block;
     const size_t lds = (((size_t)cpr * ((vec && gsz) ? 4 / gsz : 1) * sizeof(int) + 15) & ~(size_t)15) +
@@ -272,8 +272,8 @@ int32_t reconstruct_dev_impl(pqhip_codebook* cb, int slot, const void* d_codes, 
         return gather_dev(cb, slot, d_codes, code_bytes, n, c_rs, d_out, o_rs, st, err, sel_rows, n_codes, sel_scales, s_rs);
     CodebookDev& cd = cb->dev[slot];
     // OPQ (pq.rs:323-326) in ONE kernel when the rotation kernel can gather (sub-vectors of whole 16-byte pieces, P block
-    // within LDS): the reconstructed rows never exist in memory, no scratch buffer.  PQHIP_DEBUG_NO_GATHER_ROT=1: the
-    // round-2 form below (gather -> scratch -> rotate), for A/B.
+    // within LDS): the reconstructed rows never exist in memory, no scratch buffer.  Context option "opq_gather_rotation" = 0: the
+    // round-2 form below (gather -> scratch -> rotate), for A/B and for the chunk-loop tests.
     const bool fused_off = cb->ctx->opt.opq_gather_rotation.load(std::memory_order_relaxed) == 0;   // option "opq_gather_rotation"
     const int64_t code_rows = sel_rows ? n_codes : n;
     if (!fused_off && code_bytes == 1 && cb->dsub % 4 == 0 && cb->d < 65536 && cb->M * cb->K * cb->dsub < (1 << 24) &&
