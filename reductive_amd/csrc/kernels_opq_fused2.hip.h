@@ -21,20 +21,45 @@
 
 namespace pqhip {
 
-template <int DP, int T, bool SPLITK, bool ODD, bool TAIL>
+// The 32-slot form of rot8_burst (NS = 32: one column tile per block, for dimensions whose 64-column P block does not fit
+// LDS): the LDS operands of group g + 1 are requested before the two matrix instructions of group g issue.
+__device__ __forceinline__ void rot32_read(f32x2& o, const float* plane_g) { o = *reinterpret_cast<const f32x2*>(plane_g); }
+template <bool FULL>
+__device__ __forceinline__ void rot32_burst(const float* plane_b, const float* plane_next, int ng, const float (&xo)[16], f32x16& c0, f32x2& cur)
+{
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (!FULL && g >= ng) break;
+        f32x2 nxt = cur;
+        const bool last = FULL ? (g == 7) : (g + 1 == ng);
+        rot32_read(nxt, last ? plane_next : plane_b + (g + 1) * 128);
+        __builtin_amdgcn_sched_barrier(0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0], xo[2 * g], c0, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1], xo[2 * g + 1], c0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+}
+
+// NS = slots (columns) of the P block a workgroup keeps in LDS: 64 (two column tiles; d <= ~420 next to three sub-codebooks
+// of 20 floats) or 32 (one column tile: half the matrix instructions per x operand, but the block fits up to d ~ 960 --
+// d = 768 / M = 48, the size of BASELINE configs[4], which until round 4 materialised rx through the chunk loop).
+template <int DP, int T, bool SPLITK, bool ODD, bool TAIL, int NS = 64>
 __global__ __launch_bounds__(512, 2) void k_opq_encode_fused2(OpqFusedArgs a)
 {
     static_assert(DP % 2 == 0 && DP >= 2 && DP <= 32, "even sub-dimension up to 32");
     static_assert(T >= 2 && T <= 8, "2 .. 8 centroid tiles");
+    static_assert(NS == 64 || (NS == 32 && 32 % DP == 0), "64 slots, or 32 slots of whole sub-vectors");
     constexpr int NWAVE = 8;
     constexpr int S = DP / 2;            // k-steps of one distance chain
-    constexpr int NM = 64 / DP;          // subquantizers per 64-slot column block
+    constexpr int NM = NS / DP;          // subquantizers per column block
+    constexpr int GS = NS * 4;           // floats per 4-k group of the P image
     constexpr long long kKeyInit = 0x7fffffffffffffffll;
     extern __shared__ __attribute__((aligned(16))) float smem_f2[];
     const int d = a.d;
     const int ngroups = (d + 3) >> 2;                       // 4-k groups of the P image
-    float* pl = smem_f2;                                    // [ngroups + 1][64 slots][4]  (+1: pre-reads past the last group)
-    float* frag_s = pl + (size_t)(ngroups + 1) * 256;       // [NM][T][S][64]
+    float* pl = smem_f2;                                    // [ngroups + 1][NS slots][4]  (+1: pre-reads past the last group)
+    float* frag_s = pl + (size_t)(ngroups + 1) * GS;        // [NM][T][S][64]
     float* cc_s = frag_s + (size_t)NM * T * S * 64;         // [NM][256]
     long long* slot_s = reinterpret_cast<long long*>(cc_s + NM * 256);   // [8 waves][64 lanes]; exact path: 64 floats of scratch per wave
 
@@ -76,18 +101,18 @@ __global__ __launch_bounds__(512, 2) void k_opq_encode_fused2(OpqFusedArgs a)
                 if (idx < total) {
                     const int k = idx / NV4, c4 = idx - k * NV4;
                     const int inner = ((k & 1) << 1) | ((k >> 1) & 1);  // (k0, k1, k2, k3) -> (k0, k2, k1, k3)
-                    float* base = pl + (((k >> 2) << 6) << 2) + inner;
+                    float* base = pl + (k >> 2) * GS + inner;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) base[slot_of(4 * c4 + e) << 2] = v[u][e];
                 }
             }
         }
         // zero the unused slots (local columns NM * DP .. 63) of every k
-        constexpr int NPAD = 64 - NM * DP;
+        constexpr int NPAD = NS - NM * DP;
         for (int idx = tid; idx < ngroups * 4 * NPAD; idx += 512) {
             const int k = idx / (NPAD > 0 ? NPAD : 1), lc = NM * DP + idx % (NPAD > 0 ? NPAD : 1);
             const int inner = ((k & 1) << 1) | ((k >> 1) & 1);
-            pl[((((k >> 2) << 6) + slot_of(lc)) << 2) + inner] = 0.f;
+            pl[(k >> 2) * GS + (slot_of(lc) << 2) + inner] = 0.f;
         }
     }
     // fragments and norms of the block's sub-codebooks (clamped to the last real subquantizer: a ragged block re-reads it, unused)
@@ -143,7 +168,8 @@ __global__ __launch_bounds__(512, 2) void k_opq_encode_fused2(OpqFusedArgs a)
     const float* prow = row_ptr(row0);
     load_burst(sa, prow, 0, nfull > 0);
     Rot8Ops ops;
-    rot8_read(ops, plane);
+    f32x2 ops32 = {0.f, 0.f};
+    if constexpr (NS == 64) rot8_read(ops, plane); else rot32_read(ops32, plane);
     unsigned long long st_tiles = 0, st_rot = 0, st_enc = 0;
     const unsigned long long st_t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     for (;;) {
@@ -161,9 +187,14 @@ __global__ __launch_bounds__(512, 2) void k_opq_encode_fused2(OpqFusedArgs a)
             if ((bi) + 1 < nfull) load_burst(nx, prow, (bi) + 1, true);                                \
             else if (TAIL && (bi) + 1 == nfull) load_burst(nx, prow, nfull, false);                    \
             else if (has_next) load_burst(nx, pnext, 0, nfull > 0);                                    \
-            const float* pn_ = ((bi) + 1 < nb) ? plane + ((bi) + 1) * 8 * 256 : plane;                 \
-            if (!(IS_TAIL)) rot8_burst<true>(plane + (bi) * 8 * 256, pn_, 8, xo_, c0, c1, ops);        \
-            else rot8_burst<false>(plane + (bi) * 8 * 256, pn_, tail_groups, xo_, c0, c1, ops);        \
+            const float* pn_ = ((bi) + 1 < nb) ? plane + ((bi) + 1) * 8 * GS : plane;                  \
+            if constexpr (NS == 64) {                                                                  \
+                if (!(IS_TAIL)) rot8_burst<true>(plane + (bi) * 8 * GS, pn_, 8, xo_, c0, c1, ops);     \
+                else rot8_burst<false>(plane + (bi) * 8 * GS, pn_, tail_groups, xo_, c0, c1, ops);     \
+            } else {                                                                                   \
+                if (!(IS_TAIL)) rot32_burst<true>(plane + (bi) * 8 * GS, pn_, 8, xo_, c0, ops32);      \
+                else rot32_burst<false>(plane + (bi) * 8 * GS, pn_, tail_groups, xo_, c0, ops32);      \
+            }                                                                                          \
         }
 #define F2_BLOCK(bi)                                                                                   \
         if (SPLITK && (bi) > 0 && ((bi) % KB) == 0) {                                                  \

@@ -222,7 +222,7 @@ int32_t quantize_dev_impl(pqhip_codebook* cb, int slot, const float* d_x, int64_
             a.frags = cd.frags; a.cc = cd.cc; a.cb = cd.cb;
             a.out = (uint8_t*)d_codes; a.o_rs = o_rs;
             a.M = (int)cb->M; a.K = (int)cb->K; a.k_pad = cb->k_pad;
-            const int nm = 64 / DP;
+            const int nm = opq_fused2_slots(DP, cb->T, (int)cb->d) / DP;      // sub-vectors per column block (64 or 32 slots)
             a.ncb = (int)((cb->M + nm - 1) / nm);
             // tiles of 32 rows per wave: as many as leave ~8 rounds of workgroups (one per CU) for the whole launch, 4 .. 96
             // (10 M x 300, one box: 12 tiles 29.84 ms, 24: 29.57, 48: 29.40, 96: 29.24, 160: 30.6, 192 (4 rounds): 38.8 --

@@ -76,7 +76,10 @@ def _fused2(ra, q, P):
 
 
 @pytest.mark.parametrize("n,M,K,dsub", [(200_003, 15, 256, 20), (50_001, 16, 256, 16), (40_000, 20, 256, 16), (31, 15, 256, 20),
-                                        (1, 15, 256, 20), (3073, 15, 256, 20), (9000, 15, 250, 20), (6145, 16, 225, 16)])
+                                        (1, 15, 256, 20), (3073, 15, 256, 20), (9000, 15, 250, 20), (6145, 16, 225, 16),
+                                        # 32-slot P blocks (round 4): dimensions whose 64-column block does not fit LDS
+                                        (60_001, 48, 256, 16), (9_000, 32, 250, 16), (5_001, 24, 256, 16), (3073, 56, 256, 16),
+                                        (33, 48, 256, 16)])
 def test_fused2_codes_equal_oracle(ra, n, M, K, dsub):
     import torch
     d = M * dsub
@@ -95,9 +98,10 @@ def test_fused2_codes_equal_oracle(ra, n, M, K, dsub):
     assert pq.quantize_batch_device(wide[:, :d]).cpu().numpy().tobytes() == want.tobytes()
 
 
-def test_fused2_special_values_take_the_exact_path(ra):
+@pytest.mark.parametrize("M,dsub", [(15, 20), (48, 16)])
+def test_fused2_special_values_take_the_exact_path(ra, M, dsub):
     import torch
-    M, K, dsub = 15, 256, 20
+    K = 256
     d = M * dsub
     q = synth.normalish(6600, (M, K, dsub))
     P = synth.orthonormal(6601, d)
@@ -112,6 +116,7 @@ def test_fused2_special_values_take_the_exact_path(ra):
     x[704] = 0.0
     x[705] = np.float32(1e-30)
     x[4095, 0] = np.nan
+    x[4094, d - 1] = np.nan              # last column of the last column block
     pq = _fused2(ra, q, P)
     with np.errstate(all="ignore"):
         want = orc.quantize_batch(q, x, projection=P, n_threads=8)

@@ -552,14 +552,14 @@ def test_config0_plumbing_shape_10k_rows(ra):
     assert pq.reconstruct_batch(codes).tobytes() == orc.reconstruct_batch(q, codes).tobytes()
 
 
-@pytest.mark.parametrize("shape", [(15, 20, "opq_fused"), (48, 16, None)])
+@pytest.mark.parametrize("shape", [(15, 20, "opq_fused"), (48, 16, "opq_fused")])
 def test_opq_chunk_boundaries_of_a_multi_chunk_batch(ra, ctx_options, shape):
     """The TWO-KERNEL OPQ paths (rotation -> leased scratch -> encode; gather -> scratch -> rotation) walk a large batch in
     scratch chunks that are whole rounds of the rotation grid (1,179,648 rows on a 256-CU device, pqhip_opq.hip
-    opq_chunk_rows): 2.5 M rows = two full chunks and a remainder.  The paths are FORCED -- at d = 300 the default is the
-    fused kernel (one launch, no chunks), so the context options "opq_fused" / "opq_gather_rotation" are cleared; d = 768 /
-    M = 48 (the size of BASELINE configs[4]) has no fused encode instantiation and takes the chunk loop by itself -- and the
-    launch log must show one rotation and one encode launch per chunk.  Codes and un-rotated reconstructions around both
+    opq_chunk_rows): 2.5 M rows = two full chunks and a remainder.  The paths are FORCED -- the default at d = 300 and, since
+    round 4, at d = 768 / M = 48 (the size of BASELINE configs[4]) is the fused kernel (one launch, no chunks), so the context
+    options "opq_fused" / "opq_gather_rotation" are cleared -- and the launch log must show one rotation and one encode launch
+    per chunk.  (u16 / u32 codes, K > 256, odd sub-vectors and dimensions without a fused instantiation take this path by default.)  Codes and un-rotated reconstructions around both
     chunk boundaries, at the head and at the tail against the oracle; every row through encode(decode(codes)) == codes."""
     import torch
     M, dsub, opt = shape
