@@ -54,24 +54,34 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
         const bool big = (double)n_codes * (double)c_rs * code_bytes > 256.0 * 1024 * 1024;
         if ((opt == 1 || (opt != 0 && big)) && (code_bytes == 1 || code_bytes == 4)) {
             const int64_t M = cb->M;
-            const int64_t per_row = M * code_bytes + 4;
-            const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, (1ll << 30) / per_row));
+            // 1-byte codes with M <= 16: one thread per lookup writes an aligned 16-byte record (compact row stride 16)
+            const bool rec16 = code_bytes == 1 && M <= 16 && c_rs >= M;
+            const int64_t crs = rec16 ? 16 : M;
+            const int64_t per_row = crs * code_bytes + 4;
+            const int64_t chunk = std::max<int64_t>(4, std::min<int64_t>(n, (1ll << 30) / per_row)) & ~(int64_t)3;   // (scales first: codes stay 16-byte aligned)
             ScratchLease st_buf(cb, slot, st);
-            PQCHK(st_buf.acquire((size_t)chunk * per_row + 16));
-            float* sc = (float*)st_buf.ptr();                                  // [chunk] scales, then [chunk][M] codes (4-byte aligned)
+            PQCHK(st_buf.acquire((size_t)chunk * per_row + 64));
+            float* sc = (float*)st_buf.ptr();                                  // [chunk] scales, then [chunk][crs] codes
             void* cc = (void*)(sc + chunk);
+            const int64_t matrix_bytes = ((n_codes - 1) * c_rs + M) * code_bytes;
             for (int64_t r0 = 0; r0 < n; r0 += chunk) {
                 const int64_t rows = std::min<int64_t>(chunk, n - r0);
-                const unsigned g = (unsigned)std::min<int64_t>((rows * M + 255) / 256, (int64_t)cus_of(cb, slot) * 64);
-                if (code_bytes == 1)
-                    hipLaunchKernelGGL((k_select_code_rows<uint8_t>), dim3(g), dim3(256), 0, st, (const uint8_t*)d_codes, c_rs, n_codes,
+                if (rec16) {
+                    const unsigned g = (unsigned)std::min<int64_t>((rows + 255) / 256, (int64_t)cus_of(cb, slot) * 64);
+                    hipLaunchKernelGGL(k_select_code_rows16, dim3(g), dim3(256), 0, st, (const uint8_t*)d_codes, c_rs, n_codes, matrix_bytes,
                                        sel_rows + r0, rows, (int)M, (uint8_t*)cc, sel_scales, s_rs, sc, err);
-                else
-                    hipLaunchKernelGGL((k_select_code_rows<uint32_t>), dim3(g), dim3(256), 0, st, (const uint32_t*)d_codes, c_rs, n_codes,
-                                       sel_rows + r0, rows, (int)M, (uint32_t*)cc, sel_scales, s_rs, sc, err);
+                } else {
+                    const unsigned g = (unsigned)std::min<int64_t>((rows * M + 255) / 256, (int64_t)cus_of(cb, slot) * 64);
+                    if (code_bytes == 1)
+                        hipLaunchKernelGGL((k_select_code_rows<uint8_t>), dim3(g), dim3(256), 0, st, (const uint8_t*)d_codes, c_rs, n_codes,
+                                           sel_rows + r0, rows, (int)M, (uint8_t*)cc, sel_scales, s_rs, sc, err);
+                    else
+                        hipLaunchKernelGGL((k_select_code_rows<uint32_t>), dim3(g), dim3(256), 0, st, (const uint32_t*)d_codes, c_rs, n_codes,
+                                           sel_rows + r0, rows, (int)M, (uint32_t*)cc, sel_scales, s_rs, sc, err);
+                }
                 HIPCHK(hipGetLastError());
-                note_kernel("k_select_code_rows");
-                PQCHK(gather_compact(cb, slot, cc, code_bytes, rows, M, d_out + r0 * o_rs, o_rs, st, err, sel_scales ? sc : nullptr));
+                note_kernel(rec16 ? "k_select_code_rows16" : "k_select_code_rows");
+                PQCHK(gather_compact(cb, slot, cc, code_bytes, rows, crs, d_out + r0 * o_rs, o_rs, st, err, sel_scales ? sc : nullptr));
             }
             return PQHIP_OK;
         }
