@@ -55,6 +55,7 @@ extern "C" {
         n_cols: i64, x_row_stride: i64, x_col_stride: i64, out: *mut *mut pqhip_matrix) -> i32;
     pub fn pqhip_matrix_device_ptr(m: *const pqhip_matrix) -> *const f32;
     pub fn pqhip_matrix_destroy(m: *mut pqhip_matrix);
+    pub fn pqhip_ctx_set_option(ctx: *mut pqhip_ctx, name: *const c_char, value: i64) -> i32;
     pub fn pqhip_opq_train_step_f32_dev(ctx: *mut pqhip_ctx, device_slot: i32, quantizers: *mut f32,
         n_subquantizers: i64, n_centroids: i64, sub_dim: i64, projection: *const f32, d_x: *const f32,
         n_rows: i64, x_row_stride: i64, cross: *mut f32, stream: *mut c_void) -> i32;
@@ -324,6 +325,18 @@ where A: 'static + Copy, S: Data<Elem = A>,
     rc == PQHIP_OK                                         // (`_exit` bumps the generation: the centroids were rewritten in place)
 }
 
+
+/// `instances.t().dot(&reconstructed)` of `Opq::train_iteration` (opq.rs:191) on the device: `true` (default) keeps
+/// matrixmultiply's order -- one fmaf chain per 256-row block, block results added in row order -- bit for bit;
+/// `false` is a plain split-K product within 1e-5 relative of it (no per-block partial matrices: 16 ms instead of 20 ms
+/// per 10 M x 300 rows).  Builds of the crate that can train OPQ link a BLAS (Cargo.toml:37-42), whose summation order
+/// is its own; choose per deployment.
+pub fn set_cross_product_exact(exact: bool) -> bool {
+    match handles() {
+        Some(h) => unsafe { pqhip_ctx_set_option(h.ctx.0, b"cross_product_exact\0".as_ptr() as *const c_char, exact as i64) == PQHIP_OK },
+        None => false,
+    }
+}
 
 /// Instances kept in HBM for the length of an OPQ training run (`Opq::train_pq_using`, opq.rs:44-99):
 /// upload once, then one `train_step` per iteration replaces opq.rs:167-182 and the GEMM of :191.
