@@ -147,3 +147,30 @@ def test_fused2_one_million_rows_every_code(ra):
     got = pq.quantize_batch_device(x).cpu().numpy()
     want = orc.quantize_batch(q, x.cpu().numpy(), projection=P, n_threads=16)
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("M,dsub,n", [(48, 16, 3_000_001), (15, 20, 3_000_001)])
+def test_fused_and_two_kernel_paths_agree_on_every_code_of_a_large_batch(ra, ctx_options, M, dsub, n):
+    """Size-independent check of the fused kernels at batch sizes the oracle cannot walk: the fused launch (64-slot P blocks at
+    d = 300, 32-slot at d = 768 -- the size of BASELINE configs[4]) and the chunked rotation -> scratch -> encode path are two
+    independent implementations of pq.rs:276-282; all n x M codes must be equal, and both equal the oracle on head and tail."""
+    import torch
+    K = 256
+    d = M * dsub
+    q = synth.normalish(6900 + d, (M, K, dsub))
+    P = synth.orthonormal(6901 + d, d)
+    g = torch.Generator(device="cuda").manual_seed(6902)
+    x = torch.empty((n, d), device="cuda").normal_(generator=g)
+    pq = ra.Pq(P, q)
+    ra.launch_log(reset=True)
+    fused = pq.quantize_batch_device(x)
+    log = ra.launch_log(reset=True)            # (the codebook's preparation kernels run with the first call)
+    assert log.endswith("k_opq_encode_fused2") and "k_rotate" not in log, log
+    ctx_options("opq_fused", 0)
+    two = pq.quantize_batch_device(x)
+    log = ra.launch_log(reset=True)
+    assert "k_rotate_pblock" in log and "k_encode_mfma16" in log and "fused" not in log, log
+    assert torch.equal(fused, two)
+    for r0 in (0, n - 4000):
+        want = orc.quantize_batch(q, x[r0:r0 + 4000].cpu().numpy(), projection=P, n_threads=16)
+        assert fused[r0:r0 + 4000].cpu().numpy().tobytes() == want.tobytes(), r0

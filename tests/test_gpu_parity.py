@@ -1103,16 +1103,55 @@ def test_opq_train_step_gathers_the_reconstruction_inside_the_cross_product(ra):
     kernel assembles the rows of R from the codebook; other sub-vectors reconstruct first.  Same bits either way (the
     oracle reconstructs, then multiplies)."""
     import torch
-    for (n, M, K, dsub, gathered) in [(3000, 15, 256, 20, True), (1500, 3, 300, 8, True), (1200, 5, 16, 6, False)]:
+    for (n, M, K, dsub, gathered) in [(3000, 15, 256, 20, True), (1500, 3, 300, 8, True), (1200, 5, 16, 6, False),
+                                      (150_011, 15, 256, 20, True)]:          # 587 row blocks, a ragged last one
         d = M * dsub
         q0, x = _km_inputs(n, M, K, dsub, 1650 + n)
         P = synth.orthonormal(1651 + n, d)
-        want_q, want_cross = orc.opq_train_step(q0, P, x, n_threads=8)
+        want_q, want_cross = orc.opq_train_step(q0, P, x, n_threads=min(os.cpu_count() or 8, 16))
         ra.launch_log(reset=True)
         got_q, got_cross = ra.opq_train_step(q0, P, torch.from_numpy(x).cuda())
         log = ra.launch_log(reset=True)
         assert ("k_atb_rowblock<gather>" in log) == gathered and ("k_reconstruct" in log) == (not gathered), log
         assert got_q.tobytes() == want_q.tobytes() and got_cross.tobytes() == want_cross.tobytes()
+
+
+def test_two_pass_lookup_equals_one_pass_on_a_matrix_beyond_the_infinity_cache(ra, ctx_options):
+    """Lookups into a resident code matrix of 24 M rows (360 MB > 256 MB: the two-pass form is the DEFAULT there; DESIGN.md
+    section 5, lookup): every output row equals the one-kernel form's bit for bit -- split layout, strided wide matrix and
+    interleaved records -- and the oracle's on a sample; an index out of range is reported by the select pass."""
+    import torch
+    N, M, K, dsub, n = 24_000_000, 15, 256, 20, 1_500_000
+    q = synth.normalish(1250, (M, K, dsub))
+    pq = _pq(ra, q)
+    g = torch.Generator(device="cuda").manual_seed(1251)
+    codes = torch.randint(0, K, (N, M), device="cuda", dtype=torch.uint8, generator=g)
+    rows = torch.randint(0, N, (n,), device="cuda", dtype=torch.int64, generator=g)
+    scales = torch.rand((N,), device="cuda", generator=g) + 0.5
+    ra.launch_log(reset=True)
+    two = pq.reconstruct_rows_device(codes, rows, scales=scales, check=True)
+    assert ra.launch_log(reset=True).endswith("k_select_code_rows16 + k_reconstruct<scaled>")
+    ctx_options("lookup_two_pass", 0)
+    one = pq.reconstruct_rows_device(codes, rows, scales=scales, check=True)
+    assert ra.launch_log(reset=True) == "k_reconstruct<lookup>"
+    assert torch.equal(one, two)
+    pick = rows[:3000].cpu().numpy()
+    want = orc.reconstruct_batch(q, codes[rows[:3000]].cpu().numpy()) * scales[rows[:3000]].cpu().numpy()[:, None]
+    assert two[:3000].cpu().numpy().tobytes() == want.astype(np.float32).tobytes()
+    del one
+    ctx_options("lookup_two_pass", 2)
+    rec, off = ra.Pq.interleave_records(codes[:20_000_000], scales[:20_000_000])          # 640 MB of 32-byte records
+    r2 = rows % 20_000_000
+    got_r = pq.reconstruct_records_device(rec, off, r2, check=True)
+    assert "k_select_code_rows16" in ra.launch_log(reset=True)
+    ctx_options("lookup_two_pass", 0)
+    assert torch.equal(got_r, pq.reconstruct_records_device(rec, off, r2, check=True))
+    ctx_options("lookup_two_pass", 2)
+    bad = rows.clone()
+    bad[n - 1] = N
+    with pytest.raises(ra.PanicError):
+        pq.reconstruct_rows_device(codes, bad, scales=scales, check=True)
+    _ = pick
 
 
 def test_train_opq_statistical_loss(ra, kats):
