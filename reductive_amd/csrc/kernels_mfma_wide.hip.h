@@ -22,15 +22,31 @@
 
 namespace pqhip {
 
-// xx[row][m] = unrolled_dot(x[row, m dsub ..], same) -- rule 1, any dsub; one thread per (row, m)
+// xx[row][m] = unrolled_dot(x[row, m dsub ..], same) -- rule 1, any dsub.  Eight lanes per (row, m): lane l carries ndarray's
+// partial sum p[l] (elements l, 8 + l, 16 + l, .. in order), so consecutive lanes read consecutive floats; the partial sums are
+// combined in unrolled_dot's order -- s = 0; s += p0 + p4; s += p1 + p5; s += p2 + p6; s += p3 + p7 -- and the < 8 tail
+// elements follow sequentially.  (Round 3: one thread per (row, m) walking its own 0.5-1 KB -- 64 cache lines per wave
+// instruction: 3.3 TB/s, 14-19 % of a wide encode call.)
 __global__ __launch_bounds__(256) void k_row_norms(const float* __restrict__ x, int64_t n, int64_t x_rs, int M, int dsub,
                                                    float* __restrict__ xx)
 {
     const int64_t total = n * M;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = threadIdx.x & 7;
+    const int n8 = dsub >> 3;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < total; i += ((int64_t)gridDim.x * blockDim.x) >> 3) {
         const int64_t row = i / M;
         const int m = (int)(i - row * M);
-        xx[i] = norm_unrolled_global(x + row * x_rs + (int64_t)m * dsub, dsub);
+        const float* p = x + row * x_rs + (int64_t)m * dsub;
+        float acc = 0.f;
+        for (int t = 0; t < n8; ++t) {
+            const float v = p[8 * t + l];
+            acc = fadd(acc, fmul(v, v));
+        }
+        const float u = fadd(acc, __shfl_down(acc, 4, 8));          // lanes 0..3 of the group: p[l] + p[l + 4]
+        const float u0 = __shfl(u, 0, 8), u1 = __shfl(u, 1, 8), u2 = __shfl(u, 2, 8), u3 = __shfl(u, 3, 8);
+        float s = fadd(fadd(fadd(fadd(0.f, u0), u1), u2), u3);
+        for (int e = 8 * n8; e < dsub; ++e) s = fadd(s, fmul(p[e], p[e]));
+        if (l == 0) xx[i] = s;
     }
 }
 
@@ -101,37 +117,52 @@ __global__ __launch_bounds__(256, 1) void k_encode_mfma_wide(EncodeArgs a, const
         }
         const f32x2 xx2 = {xr, xr};
         long long best = 0x7fffffffffffffffll;
+        // Two centroid tiles per pass (TP = 2 when T is even): their chains are independent, so the matrix instructions of one
+        // fill the dependency gap of the other (one wave per SIMD: nothing else would)
+        constexpr int TP = (T % 2 == 0) ? 2 : 1;
 #pragma unroll 1
-        for (int t = 0; t < T; ++t) {
-            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float* af = afrag_s + (t * S) * 64 + lane;
-            // one wave per SIMD and one dependent chain: nothing hides an LDS round trip but the chain itself, so the
-            // fragments are requested PF matrix instructions (PF x 64 cycles) ahead of their use
+        for (int t0 = 0; t0 < T; t0 += TP) {
+            f32x16 acc[TP];
+            const float* af[TP];
+            // one wave per SIMD: nothing hides an LDS round trip but the chains themselves, so the fragments are requested
+            // PF matrix instructions ahead of their use
             constexpr int PF = 8;
-            float fr[PF];
+            float fr[TP][PF];
 #pragma unroll
-            for (int i = 0; i < PF; ++i) fr[i] = af[i * 64];
+            for (int u = 0; u < TP; ++u) {
+                acc[u] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                af[u] = afrag_s + ((t0 + u) * S) * 64 + lane;
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const float fa = fr[s % PF];
-                __builtin_amdgcn_sched_barrier(0);
-                if (s + PF < S) fr[s % PF] = af[(s + PF) * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, bop[s], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < PF; ++i) fr[u][i] = af[u][i * 64];
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(&cc_s[32 * t + 8 * g + 4 * h]);
-                const f32x2 c01 = {c4[0], c4[1]}, c23 = {c4[2], c4[3]};
-                f32x2 t01, t23;
-                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t01) : "v"(xx2), "v"(c01));
-                asm("v_pk_add_f32 %0, %1, %2" : "=v"(t23) : "v"(xx2), "v"(c23));
-                const float tt[4] = {t01[0], t01[1], t23[0], t23[1]};
+            for (int s = 0; s < S; ++s) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = ffma(acc[4 * g + e], -2.0f, tt[e]);
-                    const long long key = ((long long)__float_as_int(d) << 32) | (long long)(unsigned)(32 * t + lo[4 * g + e]);
-                    best = key < best ? key : best;          // signed order of {bits(d), index} = (distance, index) for d >= 0
+                for (int u = 0; u < TP; ++u) {
+                    const float fa = fr[u][s % PF];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + PF < S) fr[u][s % PF] = af[u][(s + PF) * 64];
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, bop[s], acc[u], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TP; ++u) {
+                const int t = t0 + u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(&cc_s[32 * t + 8 * g + 4 * h]);
+                    const f32x2 c01 = {c4[0], c4[1]}, c23 = {c4[2], c4[3]};
+                    f32x2 t01, t23;
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(t01) : "v"(xx2), "v"(c01));
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(t23) : "v"(xx2), "v"(c23));
+                    const float tt[4] = {t01[0], t01[1], t23[0], t23[1]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = ffma(acc[u][4 * g + e], -2.0f, tt[e]);
+                        const long long key = ((long long)__float_as_int(d) << 32) | (long long)(unsigned)(32 * t + lo[4 * g + e]);
+                        best = key < best ? key : best;          // signed order of {bits(d), index} = (distance, index) for d >= 0
+                    }
                 }
             }
         }
@@ -242,28 +273,38 @@ __global__ __launch_bounds__(256, 1) void k_encode_mfma_wide2(EncodeArgs a, cons
                 const int nkb = last_blk ? 0 : kb + 1;
                 fetch_slice(nr0, nkb, (nkb == NB - 1) ? WL : kFull);
             }
+            // the T chains of a block are independent: their matrix instructions alternate, so a dependent instruction never
+            // waits for its predecessor's last pass (one wave per SIMD: nothing else would fill the gap)
+            f32x16 acc[T];
+            const float* af[T];
+            constexpr int PF = 8;     // fragments requested PF matrix instructions ahead of their use
+            float fr[T][PF];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const float* af = afrag_s + (t * S + 128 * kb) * 64 + lane;
-                constexpr int PF = 8;     // fragments requested PF matrix instructions ahead of their use (one wave per SIMD)
-                float fr[PF];
+                acc[t] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                af[t] = afrag_s + (t * S + 128 * kb) * 64 + lane;
 #pragma unroll
-                for (int i = 0; i < PF; ++i) fr[i] = af[i * 64];
+                for (int i = 0; i < PF; ++i) fr[t][i] = af[t][i * 64];
+            }
 #pragma unroll
-                for (int s2 = 0; s2 < 128; ++s2) {
-                    if (s2 < W / 2) {
-                        const float fa = fr[s2 % PF];
+            for (int s2 = 0; s2 < 128; ++s2) {
+                if (s2 < W / 2) {
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const float fa = fr[t][s2 % PF];
                         __builtin_amdgcn_sched_barrier(0);
-                        if (s2 + PF < W / 2) fr[s2 % PF] = af[(s2 + PF) * 64];
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, bop[s2], acc, 0, 0, 0);
+                        if (s2 + PF < W / 2) fr[t][s2 % PF] = af[t][(s2 + PF) * 64];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, bop[s2], acc[t], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (kb == 0) dp[t] = acc;
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (kb == 0) dp[t] = acc[t];
                 else {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) dp[t][e] = fadd(dp[t][e], acc[e]);   // rule 2: C = fl(C + chain_b)
+                    for (int e = 0; e < 16; ++e) dp[t][e] = fadd(dp[t][e], acc[t][e]);   // rule 2: C = fl(C + chain_b)
                 }
             }
         }

@@ -41,8 +41,6 @@ int32_t gather_dev(pqhip_codebook* cb, int slot, const void* d_codes, int code_b
                    const int64_t* sel_rows, int64_t n_codes, const float* sel_scales, int64_t s_rs)
 {
     if (n == 0) return PQHIP_OK;
-    CodebookDev& cd = cb->dev[slot];
-    const int d = (int)cb->d;
     // Lookups into a resident matrix beyond the Infinity Cache (256 MB): two passes -- k_select_code_rows copies the selected
     // code rows and scales into a leased compact staging area, then this function runs again over it as a plain batch (with
     // per-row scales).  The random 15-byte reads miss the vector L1's TLB at that size, and a miss stalls the CU's whole

@@ -68,7 +68,7 @@ bool launch_encode_wide(int T, int DP, const EncodeArgs& a, const float* xx, dim
 
 void launch_row_norms(const float* x, int64_t n, int64_t x_rs, int M, int dsub, float* xx, hipStream_t st)
 {
-    const unsigned grid = (unsigned)std::min<int64_t>((n * M + 255) / 256, 256 * 64);
+    const unsigned grid = (unsigned)std::min<int64_t>((n * M * 8 + 255) / 256, 256 * 64);   // eight lanes per (row, m)
     hipLaunchKernelGGL(k_row_norms, dim3(grid), dim3(256), 0, st, x, n, x_rs, M, dsub, xx);
 }
 
