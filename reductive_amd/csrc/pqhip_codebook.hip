@@ -363,7 +363,7 @@ int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && c
 // and the first-generation fused OPQ kernel: refused since round 4.)
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {
-    if (!cb || variant < 0 || variant > 9 || variant == 3 || variant == 5) return PQHIP_EINVAL;
+    if (!cb || variant < 0 || variant > 10 || variant == 3 || variant == 5) return PQHIP_EINVAL;
     cb->variant = variant;
     return PQHIP_OK;
 }

@@ -7,6 +7,7 @@
 #include "kernels_pair16.hip.h"
 #include "encode_launch.h"
 #include "smallk_launch.h"
+#include "small16_launch.h"
 #include "wide_launch.h"
 
 using namespace pqhip;
@@ -151,6 +152,30 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         return PQHIP_OK;
     }
     if (cb->variant == 7) return PQHIP_EUNSUPPORTED;
+    // K <= 32, sub-vectors of 4 / 8 / 16 floats and 16-byte aligned rows: the 16x16x4 kernel with the
+    // transposed codebook image in LDS (kernels_small16.hip.h).  Variant 10 forces it.
+    const bool s16_fits = cb->KP != 0 && small16_has(cb->KP, (int)cb->dsub) && code_bytes == 1 && cb->norms_ok && bad_flag == nullptr &&
+                          x_rs % 4 == 0 && ((uintptr_t)d_x & 15) == 0 && small16_lds_bytes((int)cb->M, (int)cb->dsub, cb->KP) <= 96 * 1024;
+    if ((cb->variant == 10 || (cb->variant == 0 && cb->KP == 16 && cb->dsub == 8)) && s16_fits) {
+        SmallKArgs a;
+        a.x = d_x; a.n = n; a.x_rs = x_rs; a.out = (uint8_t*)d_codes; a.o_rs = o_rs;
+        a.cbt = cd.cbt; a.cc = cd.cc; a.cb = cd.cb;
+        a.M = (int)cb->M; a.K = (int)cb->K; a.k_pad = cb->k_pad;
+        // consecutive 64-row tiles per wave: the codebook image is staged once per workgroup, so as many as leave about
+        // eight rounds of workgroups for the launch
+        const int64_t n_tiles = (n + 63) / 64;
+        const int64_t wg_slots = (int64_t)cb->ctx->devs[slot]->n_cus * 4 * 8;
+        a.word_stores = (o_rs % 4 == 0 && ((uintptr_t)d_codes & 3) == 0) ? 1 : 0;
+        a.tiles_per_wave = (int)std::max<int64_t>(1, std::min<int64_t>(kSmall16TilesMax, n_tiles / (4 * wg_slots)));
+        const size_t lds = small16_lds_bytes(a.M, (int)cb->dsub, cb->KP);
+        const dim3 grid((unsigned)((n_tiles + 4 * a.tiles_per_wave - 1) / (4 * a.tiles_per_wave)));
+        if (!launch_small16(cb->KP, (int)cb->dsub, a, grid, lds, st)) return PQHIP_EUNSUPPORTED;
+        HIPCHK(hipGetLastError());
+        cb->last_kernel = "k_encode_small16";
+        note_kernel("k_encode_small16");
+        return PQHIP_OK;
+    }
+    if (cb->variant == 10) return PQHIP_EUNSUPPORTED;
     // Small codebooks: the VALU kernel reads x once, in whole row segments, and keeps the centroids on the scalar
     // path (kernels_smallk.hip.h).  Auto choice for K <= 16 with sub-vectors of <= 8 floats -- the reference's
     // own bench shape, d = 128, M = 16, K = 16: 6.3e9 vectors/s against 4.4e9 for the MFMA kernel; for wider

@@ -1,0 +1,23 @@
+// small16_launch.hip -- instantiations of k_encode_small16 (kernels_small16.hip.h).
+#include "small16_launch.h"
+#include "kernels_small16.hip.h"
+
+namespace pqhip {
+
+bool launch_small16(int KP, int dsub, const SmallKArgs& a, dim3 grid, size_t lds, hipStream_t st)
+{
+#define PQHIP_CASE(T, D)                                                                          \
+    if (KP == 16 * T && dsub == D) {                                                              \
+        if (lds > 48 * 1024 &&                                                                    \
+            hipFuncSetAttribute((const void*)k_encode_small16<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) \
+            return false;                                                                         \
+        hipLaunchKernelGGL((k_encode_small16<T, D>), grid, dim3(256), lds, st, a);                \
+        return true;                                                                              \
+    }
+    PQHIP_CASE(1, 4) PQHIP_CASE(1, 8)
+    PQHIP_CASE(2, 4) PQHIP_CASE(2, 8)
+#undef PQHIP_CASE
+    return false;
+}
+
+}  // namespace pqhip

@@ -38,9 +38,12 @@ def test_every_instantiation_matches_oracle(ra, K, dsub):
     auto = ra.Pq(None, q)
     assert auto.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy().tobytes() == want.tobytes()
     # auto: K <= 16 with sub-vectors of 2 floats (or 4 floats and >= 48 subquantizers) -> the pair kernel; other K <= 16, dsub <= 8 -> this one
+    # K <= 16 with 8-float sub-vectors and whole 16-float bursts -> the 16x16x4 kernel
     pair = K <= 16 and (dsub == 2 or (dsub == 4 and M >= 48))
+    s16 = K <= 16 and dsub == 8
     assert (auto.last_encode_kernel() == "k_encode_pair16") == pair
-    assert (auto.last_encode_kernel() == "k_encode_smallk") == (K <= 16 and dsub <= 8 and not pair)
+    assert (auto.last_encode_kernel() == "k_encode_small16") == s16
+    assert (auto.last_encode_kernel() == "k_encode_smallk") == (K <= 16 and dsub <= 8 and not pair and not s16)
     pq4 = ra.Pq(None, q)
     pq4.set_encode_variant(4)        # the MFMA kernel on the same input
     got4 = pq4.quantize_batch_device(torch.from_numpy(x).cuda())
@@ -66,9 +69,13 @@ def test_reference_bench_shape_special_values_and_strides(ra):
     with np.errstate(all="ignore"):
         want = orc.quantize_batch(q, x, n_threads=8)
     got = pq.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy()
-    assert pq.last_encode_kernel() == "k_encode_smallk"
+    assert pq.last_encode_kernel() == "k_encode_small16"
     assert got.tobytes() == want.tobytes()
     assert want[15, 3] == 2
+    pq6 = ra.Pq(None, q)
+    pq6.set_encode_variant(6)        # the scalar-path kernel on the same special values
+    assert pq6.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy().tobytes() == want.tobytes()
+    assert pq6.last_encode_kernel() == "k_encode_smallk"
     pq7 = ra.Pq(None, q)
     pq7.set_encode_variant(7)        # the pair kernel on the same special values (NaN / Inf reach both halves of a pair)
     assert pq7.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy().tobytes() == want.tobytes()
@@ -78,6 +85,7 @@ def test_reference_bench_shape_special_values_and_strides(ra):
     wide[:, :d] = torch.from_numpy(x[:5000]).cuda()
     out = torch.zeros((5000, M + 5), device="cuda", dtype=torch.uint8)
     pq.quantize_batch_device(wide[:, :d], out=out[:, :M])
+    assert pq.last_encode_kernel() == "k_encode_smallk"      # rows not 16-byte aligned: the scalar-path kernel
     assert out[:, :M].cpu().numpy().tobytes() == want[:5000].tobytes() and int(out[:, M:].sum()) == 0
     # host-buffer entry point and wider index types
     assert pq.quantize_batch(x[:20000], dtype=np.uint32).tolist() == want[:20000].astype(np.uint32).tolist()
@@ -147,3 +155,55 @@ def test_pair_kernel_is_refused_outside_its_shapes(ra):
     pq.set_encode_variant(7)
     with pytest.raises(Exception):
         pq.quantize_batch_device(torch.from_numpy(synth.normalish(7991, (100, 32))).cuda())
+
+
+@pytest.mark.parametrize("M,K,dsub,n", [(16, 16, 8, 70001), (2, 16, 8, 333), (6, 16, 8, 5000), (4, 5, 4, 10000), (12, 16, 4, 4097),
+                                        (3, 16, 8, 3000), (48, 16, 8, 20000), (16, 32, 8, 9999), (8, 17, 4, 1234), (1, 16, 8, 1),
+                                        (5, 30, 4, 777), (14, 16, 8, 6400), (16, 1, 8, 64), (32, 16, 4, 263_000), (1, 3, 4, 100),
+                                        (37, 16, 8, 5000), (75, 32, 4, 2000)])
+def test_small16_kernel(ra, M, K, dsub, n):
+    """kernels_small16.hip.h (variant 10 / auto for K <= 16 with 8-float sub-vectors): one and two centroid tiles, K < 16
+    (padding centroids), rows that end inside a 32-float stage, M not a multiple of 4 (byte tail of the code word), ragged
+    tiles, several tiles per wave, rows that coincide with centroids, NaN / Inf / huge rows -- codes equal the oracle's."""
+    import torch
+    q = synth.normalish(8800 + M + K + dsub, (M, K, dsub))
+    x = synth.normalish(8900 + M + K + dsub, (n, M * dsub))
+    if n > 40:
+        x[3, 0] = np.nan
+        x[4, M * dsub - 1] = np.inf
+        x[5] *= np.float32(1e19)
+        x[6, :dsub] = q[0, K - 1]                     # a row that IS a centroid: distance 0 up to rounding
+        x[n - 1, (M - 1) * dsub:] = q[M - 1, 0]
+        x[n - 2] = -np.inf
+        x[20:30] = 0.0
+    pq = ra.Pq(None, q)
+    pq.set_encode_variant(10)
+    with np.errstate(all="ignore"):
+        want = orc.quantize_batch(q, x, n_threads=8)
+    xd = torch.from_numpy(x).cuda()
+    got = pq.quantize_batch_device(xd).cpu().numpy()
+    assert pq.last_encode_kernel() == "k_encode_small16"
+    assert got.tobytes() == want.tobytes()
+    # 16-byte aligned strided rows and a wider code matrix: 4-byte aligned row stride (word stores), then an odd one (byte stores)
+    wide = torch.zeros((n, M * dsub + 4), device="cuda")
+    wide[:, :M * dsub] = xd
+    for extra in (4 + (-M) % 4, 3 + (-M) % 4):
+        out = torch.full((n, M + extra), 254, device="cuda", dtype=torch.uint8)
+        pq.quantize_batch_device(wide[:, :M * dsub], out=out[:, :M])
+        assert pq.last_encode_kernel() == "k_encode_small16"
+        assert out[:, :M].cpu().numpy().tobytes() == want.tobytes() and int((out[:, M:] != 254).sum()) == 0
+
+
+def test_small16_kernel_is_refused_outside_its_shapes(ra):
+    import torch
+    for shape, cols in (((4, 40, 8), 32), ((4, 16, 16), 64), ((4, 16, 12), 48)):   # K > 32; 16- and 12-float sub-vectors
+        pq = ra.Pq(None, synth.normalish(8990, shape))
+        pq.set_encode_variant(10)
+        with pytest.raises(Exception):
+            pq.quantize_batch_device(torch.from_numpy(synth.normalish(8991, (100, cols))).cuda())
+    # rows that are only 4-byte aligned
+    pq = ra.Pq(None, synth.normalish(8992, (4, 16, 8)))
+    pq.set_encode_variant(10)
+    wide = torch.zeros((100, 35), device="cuda")
+    with pytest.raises(Exception):
+        pq.quantize_batch_device(wide[:, :32])
