@@ -273,10 +273,11 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float 
  *   1  scalar anchor kernel (exact by construction, any shape)
  *   2  MFMA 32x32x2 with a lane-local (VALU) argmin          auto for sub-vectors of <= 2 floats
  *   4  MFMA 32x32x2, LDS-atomic argmin, fragments in LDS     auto wherever 9 is not taken; K > 256; k-means
- *   6  VALU kernel for small codebooks (K <= 64, u8 codes)   auto for K <= 16 with sub-vectors of <= 8 floats
+ *   6  VALU kernel for small codebooks (K <= 64, u8 codes)   auto for K <= 16, sub-vectors of <= 8 floats where 10 does not fit
  *   7  two subquantizers per matrix tile (K <= 16)           auto for 2 floats, and 4 floats from 48 subquantizers on
  *   8  OPQ only: rotation + encode in one kernel             auto where instantiated (opq_fused2_launch.h)
  *   9  MFMA 16x16x4, LDS-atomic argmin, four waves per SIMD  auto for K > 128 and sub-vectors of 12 .. 24 floats
+ *  10  MFMA 16x16x4 for small codebooks (K <= 32, 4 / 8 floats, u8 codes, 16-byte aligned rows)   auto wherever it fits
  *   (3 and 5 named kernels that rounds 1-2 shipped; PQHIP_EINVAL since round 4)                                  */
 int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);
 /* process-wide: the P-block rotation kernel where both exist (16-byte aligned rows, d % 4 == 0):

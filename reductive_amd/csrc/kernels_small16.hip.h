@@ -41,8 +41,20 @@
 
 namespace pqhip {
 
-template <int T, int DSUB>
-__global__ __launch_bounds__(256, 3) void k_encode_small16(SmallKArgs a)
+// value of lane groups 0..3 (same i16) in every lane, as the pairs (g0, g2) and (g1, g3): operands of v_pk_add_f32 with op_sel
+__device__ __forceinline__ void gather_pairs(float v, f32x2& e02, f32x2& o13)
+{
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);       // [0]: even group of the pair, [1]: odd group
+    const auto e = __builtin_amdgcn_permlane32_swap(r[0], r[0], false, false); // [0]: lower half, [1]: upper half
+    const auto d = __builtin_amdgcn_permlane32_swap(r[1], r[1], false, false);
+    e02 = (f32x2){__uint_as_float(e[0]), __uint_as_float(e[1])};
+    o13 = (f32x2){__uint_as_float(d[0]), __uint_as_float(d[1])};
+}
+
+// FULL: M is a multiple of the sub-vectors per stage (no stage runs past the end of a row)
+template <int T, int DSUB, bool FULL>
+__global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKArgs a)
 {
     static_assert((T == 1 || T == 2) && (DSUB == 4 || DSUB == 8), "no such instantiation");
     constexpr int KP = 16 * T;
@@ -117,22 +129,39 @@ __global__ __launch_bounds__(256, 3) void k_encode_small16(SmallKArgs a)
     unsigned long long flagged = 0;           // wave-uniform: tiles with rows for the exact path
     unsigned cw = 0;                          // code bytes of row `lane`, four subquantizers at a time
     // code byte of sub-vector m (already in the slots) for row `lane` of the tile at trow0
+    const unsigned lane_o = (unsigned)(lane * a.o_rs);                       // byte offset of row `lane` inside a tile's codes
     auto finalize = [&](int m, int par, int64_t trow0, int ti) {
         const long long* p = row_slots + PS * par;
         const long long k0 = p[0], k1 = p[16], k2 = p[32], k3 = p[48];
-        const long long ka = k1 < k0 ? k1 : k0;
-        const long long kb = k3 < k2 ? k3 : k2;
-        const long long kf = kb < ka ? kb : ka;
-        const float best = __int_as_float((int)(kf >> 32));
+        int hf, lf;
+        if constexpr (T == 1) {
+            // equal distances: the lower lane group holds the lower centroid index, so the high words decide alone
+            const int h0 = (int)(k0 >> 32), h1 = (int)(k1 >> 32), h2 = (int)(k2 >> 32), h3 = (int)(k3 >> 32);
+            const bool c1 = h1 < h0, c2 = h3 < h2;
+            const int ha = c1 ? h1 : h0, la = c1 ? (int)k1 : (int)k0;
+            const int hb = c2 ? h3 : h2, lb = c2 ? (int)k3 : (int)k2;
+            const bool c3 = hb < ha;
+            hf = c3 ? hb : ha;
+            lf = c3 ? lb : la;
+        } else {
+            const long long ka = k1 < k0 ? k1 : k0;
+            const long long kb = k3 < k2 ? k3 : k2;
+            const long long kf = kb < ka ? kb : ka;
+            hf = (int)(kf >> 32);
+            lf = (int)kf;
+        }
+        const float best = __int_as_float(hf);
         const bool odd = !(best >= 0.f && best < __builtin_inff());
-        const int code = odd ? 0xff : (int)(unsigned)kf;
-        if (__builtin_amdgcn_ballot_w64(odd && trow0 + lane < a.n)) flagged |= 1ull << ti;
+        const int code = odd ? 0xff : lf;
+        const int left = (int)((a.n - trow0 < 64) ? a.n - trow0 : 64);      // wave-uniform
+        const bool valid = lane < left;
+        if (__builtin_amdgcn_ballot_w64(odd && valid)) flagged |= 1ull << ti;
         const int sh = 8 * (m & 3);           // wave-uniform
         cw = (sh == 0) ? (unsigned)code : (cw | ((unsigned)code << sh));
         const bool last = m == a.M - 1;
         if (sh == 24 || last) {
-            uint8_t* o = a.out + (trow0 + lane) * a.o_rs + (m & ~3);
-            if (trow0 + lane < a.n) {
+            uint8_t* o = a.out + trow0 * a.o_rs + (m & ~3) + lane_o;
+            if (valid) {
                 if (sh == 24 && a.word_stores) *reinterpret_cast<unsigned*>(o) = cw;
                 else {                        // M not a multiple of 4 (the last one to three bytes), or codes that are not 4-byte aligned
                     for (int e = 0; e <= (m & 3); ++e) o[e] = (uint8_t)(cw >> (8 * e));
@@ -154,19 +183,26 @@ __global__ __launch_bounds__(256, 3) void k_encode_small16(SmallKArgs a)
     float af[T][S];
     f32x4 c4[T];
     auto stage = [&](f32x4 (&cur)[4][2], int64_t row0, int st, int ti) {
-        // rule 1, lane-local, and a gather over the lane groups: xs[rb][l][r] = ||sub-vector r SVL + l of row 16 rb + i16||^2
-        float xs[4][SVL][4];
+        // rule 1, lane-local (the lane holds whole sub-vectors), and a gather over the lane groups:
+        // xe[rb][l] = (||sv 0 SVL + l||^2, ||sv 2 SVL + l||^2), xo[rb][l] = (sv 1 SVL + l, sv 3 SVL + l) of row 16 rb + i16
+        f32x2 xe[4][SVL], xo[4][SVL];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int l = 0; l < SVL; ++l) {
-                float w[DSUB];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const f32x4 v = cur[rb][l * S + s];
-                    w[4 * s] = v[0]; w[4 * s + 1] = v[1]; w[4 * s + 2] = v[2]; w[4 * s + 3] = v[3];
+                float xx;
+                if constexpr (DSUB == 8) {    // p[i] = x_i^2; ((p0 + p4) + (p1 + p5)) + (p2 + p6)) + (p3 + p7)
+                    const f32x4 v0 = cur[rb][0], v1 = cur[rb][1];
+                    const f32x2 a01 = {v0[0], v0[1]}, a23 = {v0[2], v0[3]}, a45 = {v1[0], v1[1]}, a67 = {v1[2], v1[3]};
+                    const f32x2 u01 = pk_add(pk_mul(a01, a01), pk_mul(a45, a45)), u23 = pk_add(pk_mul(a23, a23), pk_mul(a67, a67));
+                    xx = fadd(fadd(fadd(u01[0], u01[1]), u23[0]), u23[1]);
+                } else {                      // four tail elements: ((x0^2 + x1^2) + x2^2) + x3^2
+                    const f32x4 v = cur[rb][l];
+                    const f32x2 a01 = {v[0], v[1]}, a23 = {v[2], v[3]};
+                    const f32x2 s01 = pk_mul(a01, a01), s23 = pk_mul(a23, a23);
+                    xx = fadd(fadd(fadd(s01[0], s01[1]), s23[0]), s23[1]);
                 }
-                gather_groups(norm_unrolled_static<DSUB>(w), xs[rb][l]);
+                gather_pairs(xx, xe[rb][l], xo[rb][l]);
             }
         // B operands, in place: bo[rb][j][r] = x[row 16 rb + i16][32 st + 8 r + 4 j + q] (piece j of lane group r)
         float bo[4][2][4];
@@ -187,7 +223,7 @@ __global__ __launch_bounds__(256, 3) void k_encode_small16(SmallKArgs a)
 #pragma unroll
         for (int c = 0; c < NSV; ++c) {
             const int m = st * NSV + c;
-            if (m < a.M) {                    // wave-uniform (false only past the end of the row in its last stage)
+            if (FULL || m < a.M) {            // wave-uniform (false only past the end of the row in its last stage)
                 const int parity = c & 1;     // NSV is even: the parity of m
                 const int r = c / SVL, l = c % SVL;   // the lane group that fetched the sub-vector, and which of its sub-vectors
                 f32x4 acc[4][T];
@@ -212,13 +248,18 @@ __global__ __launch_bounds__(256, 3) void k_encode_small16(SmallKArgs a)
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
                     long long* slot = my_slot + PS * parity + RBS * rb;
-                    const f32x2 xx2 = {xs[rb][l][r], xs[rb][l][r]};
+                    const f32x2 xp = (r & 1) ? xo[rb][l] : xe[rb][l];     // the norm is its low (r < 2) or high half
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         const f32x2 c01 = {cm[t][0], cm[t][1]}, c23 = {cm[t][2], cm[t][3]};
                         f32x2 t01, t23;
-                        asm("v_pk_add_f32 %0, %1, %2" : "=v"(t01) : "v"(xx2), "v"(c01));
-                        asm("v_pk_add_f32 %0, %1, %2" : "=v"(t23) : "v"(xx2), "v"(c23));
+                        if (r < 2) {
+                            asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t01) : "v"(xp), "v"(c01));
+                            asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t23) : "v"(xp), "v"(c23));
+                        } else {
+                            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t01) : "v"(xp), "v"(c01));
+                            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t23) : "v"(xp), "v"(c23));
+                        }
                         const float tt[4] = {t01[0], t01[1], t23[0], t23[1]};
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {

@@ -8,10 +8,17 @@ bool launch_small16(int KP, int dsub, const SmallKArgs& a, dim3 grid, size_t lds
 {
 #define PQHIP_CASE(T, D)                                                                          \
     if (KP == 16 * T && dsub == D) {                                                              \
-        if (lds > 48 * 1024 &&                                                                    \
-            hipFuncSetAttribute((const void*)k_encode_small16<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) \
-            return false;                                                                         \
-        hipLaunchKernelGGL((k_encode_small16<T, D>), grid, dim3(256), lds, st, a);                \
+        if (a.M % (32 / D) == 0) {                                                                \
+            if (lds > 48 * 1024 &&                                                                \
+                hipFuncSetAttribute((const void*)k_encode_small16<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) \
+                return false;                                                                     \
+            hipLaunchKernelGGL((k_encode_small16<T, D, true>), grid, dim3(256), lds, st, a);      \
+        } else {                                                                                  \
+            if (lds > 48 * 1024 &&                                                                \
+                hipFuncSetAttribute((const void*)k_encode_small16<T, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) \
+                return false;                                                                     \
+            hipLaunchKernelGGL((k_encode_small16<T, D, false>), grid, dim3(256), lds, st, a);     \
+        }                                                                                         \
         return true;                                                                              \
     }
     PQHIP_CASE(1, 4) PQHIP_CASE(1, 8)

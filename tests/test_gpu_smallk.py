@@ -38,9 +38,9 @@ def test_every_instantiation_matches_oracle(ra, K, dsub):
     auto = ra.Pq(None, q)
     assert auto.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy().tobytes() == want.tobytes()
     # auto: K <= 16 with sub-vectors of 2 floats (or 4 floats and >= 48 subquantizers) -> the pair kernel; other K <= 16, dsub <= 8 -> this one
-    # K <= 16 with 8-float sub-vectors and whole 16-float bursts -> the 16x16x4 kernel
+    # K <= 32 with 4- or 8-float sub-vectors -> the 16x16x4 kernel; other K <= 16, dsub <= 8 -> the scalar-path kernel
     pair = K <= 16 and (dsub == 2 or (dsub == 4 and M >= 48))
-    s16 = K <= 16 and dsub == 8
+    s16 = K <= 32 and dsub in (4, 8) and not pair
     assert (auto.last_encode_kernel() == "k_encode_pair16") == pair
     assert (auto.last_encode_kernel() == "k_encode_small16") == s16
     assert (auto.last_encode_kernel() == "k_encode_smallk") == (K <= 16 and dsub <= 8 and not pair and not s16)
