@@ -126,6 +126,8 @@ def lib():
     L.pqhip_launch_log.argtypes = []
     L.pqhip_launch_log_reset.restype = None
     L.pqhip_launch_log_reset.argtypes = []
+    L.pqhip_vor2_tables_host.restype = i32
+    L.pqhip_vor2_tables_host.argtypes = [vp, i64, i64, vp, i64, vp, ctypes.POINTER(i64)]
     L.pqhip_selftest_mfma_chain.restype = i32
     L.pqhip_selftest_mfma_chain.argtypes = [vp, i32, i32, i32, ctypes.c_uint64,
                                             ctypes.POINTER(i64)]
@@ -146,5 +148,5 @@ EXPORTS = [
     "pqhip_opq_train_step_f32_dev", "pqhip_at_dot_b_f32_dev", "pqhip_rotate_f32_dev",
     "pqhip_matrix_upload_f32", "pqhip_matrix_device_ptr", "pqhip_matrix_rows", "pqhip_matrix_destroy",
     "pqhip_set_encode_variant", "pqhip_set_rotation_variant", "pqhip_last_encode_kernel", "pqhip_selftest_mfma_chain",
-    "pqhip_ctx_set_option", "pqhip_launch_log", "pqhip_launch_log_reset",
+    "pqhip_ctx_set_option", "pqhip_launch_log", "pqhip_launch_log_reset", "pqhip_vor2_tables_host",
 ]

@@ -6,6 +6,7 @@
 #include "kernels_mfma.hip.h"     // kBigNorm
 #include "kernels_prep.hip.h"
 #include "smallk_launch.h"        // smallk_has / smallk_kp
+#include "vor2_prep.h"
 
 using namespace pqhip;
 
@@ -281,6 +282,13 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
             for (int64_t c = 0; c < cb->d; ++c) PT[c * cb->d + k] = projection[k * cb->d + c];
     }
 
+    // 2-float sub-vectors: candidate tables (Pq handles only: the centroids of a k-means handle move)
+    Vor2Tables vor2;
+    if (dsub == 2 && K <= 256 && only_slot < 0 && T != 0 && vor2_build(quantizers, M, K, vor2)) {
+        cb->vor2 = true;
+        cb->vor2_max_region_words = vor2.max_region_words;
+    }
+
     cb->dev.resize(ctx->devs.size());
     for (CodebookDev& cd : cb->dev) cd.pool.resize((size_t)kScratchPoolMax * kScratchLevels);   // fixed size: elements never move
     bool norms_ok = true;
@@ -298,6 +306,12 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
         if (T) HIPCHK(hipMalloc((void**)&cd.frags, (size_t)(M * groups * T * S * 64) * sizeof(float)));
         if (cb->KP) HIPCHK(hipMalloc((void**)&cd.cbt, (size_t)(M * dsub * cb->KP) * sizeof(float)));
         if (cb->pair16) HIPCHK(hipMalloc((void**)&cd.fragp, (size_t)(((M + 1) / 2) * (dsub * 64 + 32)) * sizeof(float)));
+        if (cb->vor2) {
+            HIPCHK(hipMalloc((void**)&cd.vor2_tab, vor2.words.size() * sizeof(uint32_t)));
+            HIPCHK(hipMalloc((void**)&cd.vor2_off, vor2.region_off.size() * sizeof(uint32_t)));
+            HIPCHK(hipMemcpyAsync(cd.vor2_tab, vor2.words.data(), vor2.words.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(cd.vor2_off, vor2.region_off.data(), vor2.region_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        }
         if (projection) {
             const size_t pb = (size_t)cb->d * cb->d * sizeof(float);
             HIPCHK(hipMalloc((void**)&cd.P, pb));
@@ -340,6 +354,8 @@ void pqhip_codebook_destroy(pqhip_codebook* cb)
         if (cd.cc) (void)hipFree(cd.cc);
         if (cd.cbt) (void)hipFree(cd.cbt);
         if (cd.fragp) (void)hipFree(cd.fragp);
+        if (cd.vor2_tab) (void)hipFree(cd.vor2_tab);
+        if (cd.vor2_off) (void)hipFree(cd.vor2_off);
         if (cd.P) (void)hipFree(cd.P);
         if (cd.PT) (void)hipFree(cd.PT);
         if (cd.err) (void)hipFree(cd.err);
@@ -363,8 +379,23 @@ int32_t pqhip_codebook_has_projection(const pqhip_codebook* cb) { return cb && c
 // and the first-generation fused OPQ kernel: refused since round 4.)
 int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
 {
-    if (!cb || variant < 0 || variant > 10 || variant == 3 || variant == 5) return PQHIP_EINVAL;
+    if (!cb || variant < 0 || variant > 11 || variant == 3 || variant == 5) return PQHIP_EINVAL;
     cb->variant = variant;
+    return PQHIP_OK;
+}
+
+int32_t pqhip_vor2_tables_host(const float* quantizers, int64_t M, int64_t K, uint32_t* words_out, int64_t words_cap,
+                               uint32_t* region_off_out, int64_t* n_words)
+{
+    if (!quantizers || !n_words || M <= 0 || K <= 0) return PQHIP_EINVAL;
+    Vor2Tables t;
+    if (!vor2_build(quantizers, M, K, t)) return PQHIP_EUNSUPPORTED;
+    *n_words = (int64_t)t.words.size();
+    if (words_out) {
+        if (words_cap < (int64_t)t.words.size()) return PQHIP_EINVAL;
+        std::copy(t.words.begin(), t.words.end(), words_out);
+    }
+    if (region_off_out) std::copy(t.region_off.begin(), t.region_off.end(), region_off_out);
     return PQHIP_OK;
 }
 

@@ -8,6 +8,7 @@
 #include "encode_launch.h"
 #include "smallk_launch.h"
 #include "small16_launch.h"
+#include "vor2_launch.h"
 #include "wide_launch.h"
 
 using namespace pqhip;
@@ -116,6 +117,26 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     } else
     if (cb->groups > 1 && cb->variant != 1 && cb->norms_ok && code_bytes == 4)
         return encode_grouped_dev(cb, slot, d_x, n, x_rs, d_codes, o_rs, st);
+    // 2-float sub-vectors, K <= 256: only the centroids that can win in the point's grid cell are evaluated (kernels_vor2.hip.h;
+    // the tables exist for Pq handles whose centroids are finite and within range).  Variant 11 forces it.
+    // Auto above 16 centroids (tools: bench.py --d .. --variant 0 / 2 / 4, vectors/s against the best kernel that evaluates every
+    // centroid): d=20 M=10 K=128 (the reference's test shape) 1.22e10 / 5.3e9, K=256 9.3e9 / 2.5e9, K=32 1.44e10 / 1.31e10;
+    // d=64 M=32 K=128 3.3e9 / 1.75e9; d=300 M=150 K=256 3.4e8 / 1.7e8.  Up to 16 centroids the pair kernel below is faster
+    // (d=128 M=64 K=16: 3.6e9 against 1.8e9 here).
+    if ((cb->variant == 11 || (cb->variant == 0 && cb->K > 16)) && cb->vor2 && code_bytes == 1 && cb->norms_ok && bad_flag == nullptr) {
+        Vor2Launch l;
+        l.x = d_x; l.n = n; l.x_rs = x_rs; l.out = (uint8_t*)d_codes; l.o_rs = o_rs;
+        l.cb = cd.cb; l.cc = cd.cc; l.tab = cd.vor2_tab; l.off = cd.vor2_off;
+        l.M = (int)cb->M; l.K = (int)cb->K; l.k_pad = cb->k_pad; l.max_region_words = cb->vor2_max_region_words;
+        l.n_cus = cb->ctx->devs[slot]->n_cus;
+        if (launch_vor2(l, st)) {
+            HIPCHK(hipGetLastError());
+            cb->last_kernel = "k_encode_vor2";
+            note_kernel("k_encode_vor2");
+            return PQHIP_OK;
+        }
+    }
+    if (cb->variant == 11) return PQHIP_EUNSUPPORTED;
     // K <= 16 with sub-vectors of 2 / 4 / 8 / 16 floats: one matrix tile serves two subquantizers, x is read once in whole
     // lines (kernels_pair16.hip.h).  Variant 7 forces it; variants 1..6 keep the others.
     // Measured (tools/smallk_ab.sh, one box, vectors/s pair / VALU kernel / default MFMA kernel): d=128 M=64 (dsub 2) 3.59e9 / 3.31e9 /

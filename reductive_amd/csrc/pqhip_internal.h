@@ -262,6 +262,8 @@ struct CodebookDev {
     float* cc = nullptr;     // [M][k_pad]
     float* cbt = nullptr;    // [M][dsub][KP] transposed image for the small-codebook kernel (K <= 64)
     float* fragp = nullptr;  // [NP][dsub][64] block-diagonal pair fragments + [NP][2][16] norms (K <= 16: kernels_pair16.hip.h)
+    uint32_t* vor2_tab = nullptr;   // dsub == 2, K <= 256: candidate tables of kernels_vor2.hip.h (vor2_prep.h) ...
+    uint32_t* vor2_off = nullptr;   // ... and the [M + 1] word offsets of the regions
     float* P = nullptr;      // [d][d]   x.dot(P)
     float* PT = nullptr;     // [d][d]   r.dot(P^T)
     int* err = nullptr;      // [0] unused, [1] "some ||c||^2 not finite" (k_check_norms), [2 .. 2 + kErrSlots):
@@ -296,6 +298,8 @@ struct pqhip_codebook {
     bool wide = false;      // 128 < dsub <= 1,024: groups of 32 T <= 128 centroids through k_encode_mfma_wide / _wide2 (kernels_mfma_wide.hip.h)
     int KP = 0;             // small codebooks (K <= 64, instantiated dsub): padded centroid count of the VALU kernel
     bool pair16 = false;    // K <= 16 and dsub in {2, 4, 8, 16}: the two-subquantizers-per-tile kernel applies
+    bool vor2 = false;      // dsub == 2, K <= 256, immutable centroids within range: the candidate-list kernel applies
+    uint32_t vor2_max_region_words = 0;
     int groups = 1;         // K > 256: groups of 256 centroids (8 tiles each) merged through 64-bit keys
     bool norms_ok = false;  // all ||c||^2 finite and < 2^100
     int variant = 0;        // pqhip_set_encode_variant

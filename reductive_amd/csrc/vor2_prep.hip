@@ -1,0 +1,152 @@
+// vor2_prep.hip -- host-side builder of the candidate tables of kernels_vor2.hip.h (see vor2_prep.h for the argument).
+#include "vor2_prep.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace pqhip {
+namespace {
+
+constexpr double kU = 1.0 / 16777216.0;           // 2^-24
+constexpr int kCoarseG = 16;
+constexpr size_t kMaxListBytes = 48 * 1024;       // per subquantizer
+
+struct Axis {
+    float lo, inv;                                // what the kernel uses
+    int G;
+    // real interval mapped to cell i, widened
+    void cell(int i, double& a, double& b) const
+    {
+        const double w = 1.0 / (double)inv;
+        a = (double)lo + (i - 1.0 / 1024) * w;
+        b = (double)lo + (i + 1 + 1.0 / 1024) * w;
+    }
+};
+
+inline uint32_t f2u(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+// centroids that can be a minimum somewhere in [a0, b0] x [a1, b1], ascending
+void candidates(const double* c, const double* cc, int K, double ccmax, double a0, double b0, double a1, double b1,
+                std::vector<int>& keep, std::vector<double>& v)
+{
+    const double px[4] = {a0, a0, b0, b0}, py[4] = {a1, b1, a1, b1};
+    const double p2 = std::max(a0 * a0, b0 * b0) + std::max(a1 * a1, b1 * b1);
+    const double E2 = 2.0 * (16.0 * kU * (p2 + ccmax) + 7.5e-37);          // 2 E(R)
+    // first filter: min_R (D_j - D_i) >= min_R D_j - max_R D_i with D the distance itself -- rectangle to point, farthest corner
+    double best_upper = INFINITY;
+    for (int j = 0; j < K; ++j) {
+        const double f0 = std::max(std::fabs(a0 - c[2 * j]), std::fabs(b0 - c[2 * j]));
+        const double f1 = std::max(std::fabs(a1 - c[2 * j + 1]), std::fabs(b1 - c[2 * j + 1]));
+        best_upper = std::min(best_upper, f0 * f0 + f1 * f1);
+    }
+    std::vector<int> surv;
+    for (int j = 0; j < K; ++j) {
+        const double n0 = std::max(std::max(a0 - c[2 * j], c[2 * j] - b0), 0.0);
+        const double n1 = std::max(std::max(a1 - c[2 * j + 1], c[2 * j + 1] - b1), 0.0);
+        if (!(n0 * n0 + n1 * n1 > best_upper + E2)) surv.push_back(j);
+    }
+    // v[j][corner] = D_j(corner) - |corner|^2 (linear in the corner) for the survivors
+    v.resize((size_t)4 * K);
+    for (int j : surv)
+        for (int q = 0; q < 4; ++q) v[(size_t)4 * j + q] = cc[j] - 2.0 * (px[q] * c[2 * j] + py[q] * c[2 * j + 1]);
+    // pairwise among the survivors (any witness is a valid one)
+    keep.clear();
+    for (int j : surv) {
+        bool dominated = false;
+        for (int i : surv) {
+            if (i == j) continue;
+            double mn = INFINITY;
+            for (int q = 0; q < 4; ++q) mn = std::min(mn, v[(size_t)4 * j + q] - v[(size_t)4 * i + q]);
+            if (mn > E2) { dominated = true; break; }
+        }
+        if (!dominated) keep.push_back(j);
+    }
+}
+
+}  // namespace
+
+bool vor2_build(const float* quantizers, int64_t M, int64_t K, Vor2Tables& out)
+{
+    out.words.clear();
+    out.region_off.assign(1, 0u);
+    out.max_region_words = 0;
+    if (K < 1 || K > 256) return false;
+    // cells per axis of the fine grid: finer cells shorten the lists, but the tables of a workgroup's subquantizers share LDS with
+    // its occupancy (d = 20, M = 10, K = 128, 10 M rows on one box: G = 16 0.94 ms, 24 0.78-0.80, 32 0.87-0.90, 48 0.97, 64 1.82)
+    const int G = K >= 192 ? 32 : K >= 48 ? 24 : 16;
+    std::vector<double> c((size_t)2 * K), cc((size_t)K), v;
+    std::vector<int> keep;
+    for (int64_t m = 0; m < M; ++m) {
+        const float* q = quantizers + m * K * 2;
+        double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY}, ccmax = 0.0;
+        for (int j = 0; j < K; ++j) {
+            for (int a = 0; a < 2; ++a) {
+                const double val = (double)q[2 * j + a];
+                if (!std::isfinite(val) || std::fabs(val) > 1.0995116e12) return false;     // 2^40
+                c[2 * j + a] = val;
+                lo[a] = std::min(lo[a], val);
+                hi[a] = std::max(hi[a], val);
+            }
+            cc[j] = c[2 * j] * c[2 * j] + c[2 * j + 1] * c[2 * j + 1];
+            ccmax = std::max(ccmax, cc[j]);
+        }
+        Axis fine[2], coarse[2];
+        for (int a = 0; a < 2; ++a) {
+            double s = hi[a] - lo[a];
+            const double mag = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
+            s = std::max(s, mag * 9.5367431640625e-7);                                       // 2^-20 of the magnitude
+            if (!(s >= 9.094947e-13)) s = 9.094947e-13;                                      // 2^-40
+            fine[a].G = G;
+            fine[a].lo = (float)(lo[a] - 0.5 * s);
+            fine[a].inv = (float)(G / (2.0 * s));
+            coarse[a].G = kCoarseG;
+            coarse[a].lo = (float)(lo[a] - 8.0 * s);
+            coarse[a].inv = (float)(kCoarseG / (17.0 * s));
+            if (!std::isfinite(fine[a].inv) || !std::isfinite(coarse[a].inv) || !(fine[a].inv > 0.f) || !(coarse[a].inv > 0.f)) return false;
+        }
+        std::vector<uint32_t> region((size_t)kVor2HeaderWords + (size_t)G * G + (size_t)kCoarseG * kCoarseG, 0u);
+        std::vector<uint8_t> lists;
+        region[0] = f2u(fine[0].lo); region[1] = f2u(fine[0].inv); region[2] = f2u(fine[1].lo); region[3] = f2u(fine[1].inv);
+        region[4] = f2u((float)G);
+        region[5] = f2u(coarse[0].lo); region[6] = f2u(coarse[0].inv); region[7] = f2u(coarse[1].lo); region[8] = f2u(coarse[1].inv);
+        region[9] = f2u((float)kCoarseG);
+        region[10] = (uint32_t)kVor2HeaderWords;
+        region[11] = (uint32_t)(kVor2HeaderWords + G * G);
+        region[13] = (uint32_t)G;
+        region[14] = (uint32_t)kCoarseG;
+        for (int level = 0; level < 2; ++level) {
+            const Axis* ax = level == 0 ? fine : coarse;
+            const int g = ax[0].G;
+            const uint32_t base = region[10 + level];
+            for (int i0 = 0; i0 < g; ++i0)
+                for (int i1 = 0; i1 < g; ++i1) {
+                    double a0, b0, a1, b1;
+                    ax[0].cell(i0, a0, b0);
+                    ax[1].cell(i1, a1, b1);
+                    candidates(c.data(), cc.data(), (int)K, ccmax, a0, b0, a1, b1, keep, v);
+                    if (keep.empty() || keep.size() > 256 || lists.size() + keep.size() > kMaxListBytes) return false;
+                    // (count 1 .. 256 in 9 bits)
+                    region[base + (uint32_t)(i0 * g + i1)] = ((uint32_t)lists.size() << 9) | (uint32_t)keep.size();
+                    for (int j : keep) lists.push_back((uint8_t)j);
+                    while (lists.size() % 4) lists.push_back((uint8_t)keep.back());   // whole words: the kernel reads four indices at a time
+                }
+        }
+        region[12] = (uint32_t)(region.size() * 4);
+        while (lists.size() % 4) lists.push_back(0);
+        const size_t w0 = region.size();
+        region.resize(w0 + lists.size() / 4);
+        std::memcpy(region.data() + w0, lists.data(), lists.size());
+        out.words.insert(out.words.end(), region.begin(), region.end());
+        out.region_off.push_back((uint32_t)out.words.size());
+        out.max_region_words = std::max<uint32_t>(out.max_region_words, (uint32_t)region.size());
+    }
+    return true;
+}
+
+}  // namespace pqhip

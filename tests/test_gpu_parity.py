@@ -134,7 +134,7 @@ def test_encode_matches_oracle(ra, shape, variant):
     assert got.tobytes() == want.tobytes()
     if variant == 0 and K <= 256 and dsub <= 32:
         # auto: one of the small-codebook kernels where instantiated, else an MFMA kernel
-        assert pq.last_encode_kernel().startswith(("k_encode_mfma", "k_encode_smallk", "k_encode_small16", "k_encode_pair16"))
+        assert pq.last_encode_kernel().startswith(("k_encode_mfma", "k_encode_smallk", "k_encode_small16", "k_encode_pair16", "k_encode_vor2"))
         assert (pq.last_encode_kernel() == "k_encode_mfma16") == (_has_mfma16(K, dsub) and K > 128 and 12 <= dsub <= 24)
     if variant == 9:
         assert pq.last_encode_kernel() == "k_encode_mfma16"

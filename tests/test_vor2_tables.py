@@ -1,0 +1,173 @@
+"""Candidate tables of the 2-float sub-vector encode kernel (reductive_amd/csrc/vor2_prep.h, kernels_vor2.hip.h), checked on
+the CPU: the tables are built by the library's host code (no GPU needed), the kernel's walk -- cell from the float operations
+fl(fl(x - lo) * inv), the cell's list, strict `<` over the listed centroids in ascending order with the CANON-F32 distance --
+is restated in numpy, and the result must be the oracle's code (oracle/pq_oracle: every centroid evaluated) for every point,
+i.e. the winner is always on the list.  Reference shape: pq.rs:431-440 (d = 20, M = 10, K = 128)."""
+import numpy as np
+import pytest
+
+import synth
+from oracle import pq_oracle as orc
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import os
+    import reductive_amd
+    if not os.path.exists(reductive_amd.lib_path()):
+        reductive_amd.build()
+    return reductive_amd
+
+
+def walk(words, off, q, x):
+    """The kernel's walk, vectorised over rows: returns codes [n][M] with -1 where the row takes the exact path."""
+    M, K, _ = q.shape
+    n = x.shape[0]
+    out = np.full((n, M), -1, dtype=np.int64)
+    lists_seen = []
+    f32 = np.float32
+    for m in range(M):
+        r = words[off[m]:off[m + 1]]
+        hf = r.view(np.float32)
+        x0 = x[:, 2 * m].astype(f32)
+        x1 = x[:, 2 * m + 1].astype(f32)
+        with np.errstate(all="ignore"):
+            t0 = (x0 - hf[0]) * hf[1]
+            t1 = (x1 - hf[2]) * hf[3]
+            u0 = (x0 - hf[5]) * hf[6]
+            u1 = (x1 - hf[7]) * hf[8]
+            in_f = (t0 >= 0) & (t0 < hf[4]) & (t1 >= 0) & (t1 < hf[4])
+            in_c = (u0 >= 0) & (u0 < hf[9]) & (u1 >= 0) & (u1 < hf[9])
+        G, CG = int(r[13]), int(r[14])
+        s0 = np.where(in_f, t0, np.where(in_c, u0, 0)).astype(np.int64)
+        s1 = np.where(in_f, t1, np.where(in_c, u1, 0)).astype(np.int64)
+        ci = np.where(in_f, int(r[10]) + s0 * G + s1, int(r[11]) + s0 * CG + s1)
+        cw = r[ci]
+        ok = in_f | in_c
+        cnt = np.where(ok, cw & 511, 0).astype(np.int64)
+        lofs = (cw >> 9).astype(np.int64)
+        lb = r.view(np.uint8)[int(r[12]):]                   # (lists are padded to whole words; the walk ignores the padding)
+        xx = (x0 * x0 + x1 * x1).astype(f32)
+        best = np.full(n, np.inf, dtype=f32)
+        bj = np.full(n, -1, dtype=np.int64)
+        c = q[m].astype(f32)
+        cc = (c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1]).astype(f32)
+        for i in range(int(cnt.max()) if n else 0):
+            act = i < cnt
+            j = lb[np.minimum(lofs + i, lb.size - 1)].astype(np.int64)
+            # dp = fma(x1, c1, fl(x0 c0)); d = fma(dp, -2, fl(xx + cc)): exact in float64 (24-bit products), then one rounding
+            p0 = (x0 * c[j, 0]).astype(f32)
+            dp = (x1.astype(np.float64) * c[j, 1].astype(np.float64) + p0.astype(np.float64)).astype(f32)
+            t = (xx + cc[j]).astype(f32)
+            d = (t.astype(np.float64) - 2.0 * dp.astype(np.float64)).astype(f32)
+            take = act & (d < best)
+            best = np.where(take, d, best)
+            bj = np.where(take, j, bj)
+        out[:, m] = bj
+        lists_seen.append(cnt[ok].mean() if ok.any() else 0.0)
+    return out, lists_seen
+
+
+def check(ra, q, x, min_fast=0.0):
+    t = ra.vor2_tables(q)
+    assert t is not None
+    words, off = t
+    with np.errstate(all="ignore"):
+        want = orc.quantize_batch(q, x, n_threads=8).astype(np.int64)
+        got, mean_list = walk(words, off, q, x)
+    fast = got >= 0
+    assert (got[fast] == want[fast]).all(), np.argwhere(fast & (got != want))[:5]
+    assert fast.mean() >= min_fast, fast.mean()
+    return mean_list
+
+
+def test_reference_test_shape_gaussian_data(ra):
+    M, K = 10, 128                                           # pq.rs:431-440
+    x = synth.normalish(9100, (200_000, 2 * M))
+    q = np.stack([x[np.arange(K) * 131 + 7 * m, 2 * m:2 * m + 2] for m in range(M)])   # data points as centroids
+    mean_list = check(ra, q, x, min_fast=1.0)
+    assert max(mean_list) < 16, mean_list                    # a handful of the 128 centroids per sub-vector
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 17, 47, 48, 128, 255, 256])
+def test_every_k_uniform_data_over_both_grids(ra, K):
+    M = 3
+    rng = np.random.default_rng(9200 + K)
+    q = rng.standard_normal((M, K, 2)).astype(np.float32)
+    # uniform over 20 x the centroids' range: fine cells, coarse cells and rows outside both
+    x = (rng.random((60_000, 2 * M)).astype(np.float32) - np.float32(0.5)) * np.float32(60.0)
+    x[:20_000] = rng.standard_normal((20_000, 2 * M)).astype(np.float32)
+    check(ra, q, x)
+
+
+def test_points_on_cell_boundaries_and_on_centroids(ra):
+    M, K = 2, 128
+    rng = np.random.default_rng(9300)
+    q = rng.standard_normal((M, K, 2)).astype(np.float32)
+    words, off = ra.vor2_tables(q)
+    rows = []
+    for m in range(M):
+        hf = words[off[m]:off[m + 1]].view(np.float32)
+        G = int(words[off[m] + 13])
+        for lo, inv, g in ((hf[0], hf[1], G), (hf[5], hf[6], 16)):
+            edges = (np.float64(lo) + np.arange(g + 1) / np.float64(inv)).astype(np.float32)
+            for e in edges:                                  # the edge, and its float neighbours
+                for v in (e, np.nextafter(e, np.float32(-np.inf)), np.nextafter(e, np.float32(np.inf))):
+                    rows.append(v)
+    vals = np.array(rows, dtype=np.float32)
+    a, b = np.meshgrid(vals, vals)
+    x = np.zeros((a.size, 2 * M), dtype=np.float32)
+    for m in range(M):
+        x[:, 2 * m] = a.ravel()
+        x[:, 2 * m + 1] = np.roll(b.ravel(), 17 * m)
+    check(ra, q, x[:400_000])
+    # rows that ARE centroids, midpoints of centroid pairs (exact ties up to rounding), duplicated centroids
+    q2 = q.copy()
+    q2[0, 100] = q2[0, 3]
+    q2[1, 5] = q2[1, 77]
+    mid = ((q2[:, :64] + q2[:, 64:]) * np.float32(0.5))
+    x2 = np.concatenate([q2.transpose(1, 0, 2).reshape(K, 2 * M), mid.transpose(1, 0, 2).reshape(64, 2 * M)])
+    check(ra, q2, x2, min_fast=1.0)
+
+
+@pytest.mark.parametrize("kind", ["identical", "collinear", "outlier", "tiny", "large", "two_clusters", "lattice"])
+def test_adversarial_codebooks(ra, kind):
+    M, K = 2, 64
+    rng = np.random.default_rng(9400)
+    q = rng.standard_normal((M, K, 2)).astype(np.float32)
+    scale = np.float32(1.0)
+    if kind == "identical":
+        q[:] = q[:, :1]
+    elif kind == "collinear":
+        q[:, :, 1] = q[:, :, 0] * np.float32(0.5)
+    elif kind == "outlier":
+        q[:, 0] = np.float32(1e4)
+    elif kind == "tiny":
+        scale = np.float32(1e-18)
+    elif kind == "large":
+        scale = np.float32(3e9)
+    elif kind == "two_clusters":
+        q[:, :32] += np.float32(1000.0)
+    elif kind == "lattice":                                  # many exact ties
+        g = np.arange(8, dtype=np.float32)
+        q[:] = np.stack(np.meshgrid(g, g), -1).reshape(64, 2)
+    q = q * scale
+    x = rng.standard_normal((40_000, 2 * M)).astype(np.float32) * np.float32(2.0) * scale
+    if kind == "two_clusters":
+        x[:20_000] += np.float32(1000.0)
+    if kind == "lattice":
+        x = (rng.integers(-2, 20, (40_000, 2 * M)).astype(np.float32) * np.float32(0.5))
+    if kind == "outlier":
+        x[:1000] = np.float32(1e4) + rng.standard_normal((1000, 2 * M)).astype(np.float32)
+    if kind == "identical" and ra.vor2_tables(q) is None:
+        return                                               # every cell lists every centroid: the tables are refused (size)
+    check(ra, q, x)
+
+
+def test_ineligible_codebooks(ra):
+    q = synth.normalish(9500, (2, 16, 2))
+    for bad in (np.nan, np.inf, np.float32(3e12)):
+        b = q.copy()
+        b[1, 3, 0] = bad
+        assert ra.vor2_tables(b) is None
+    assert ra.vor2_tables(synth.normalish(9501, (1, 257, 2))) is None
