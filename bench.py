@@ -466,6 +466,16 @@ def main():
                 except Exception as e:            # a sub-config must never take the headline line down
                     subs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             rec["configs"] = subs
+            # the reference's OWN shapes (not BASELINE configs): its criterion bench (benches/pq.rs:9-10) and its statistical
+            # test (pq.rs:431-440), 10 M rows each, same record form
+            refs = {}
+            for key, (sd, sm, sk) in (("benches_pq_rs_d128_M16_K16", (128, 16, 16)), ("pq_rs_test_d20_M10_K128", (20, 10, 128))):
+                try:
+                    r = b.run("encode", 10_000_000, sd, sm, sk, max(1, min(args.steps, args.sub_steps)), min(2, max(1, args.warmup)))
+                    refs[key] = record("encode", r, 1)
+                except Exception as e:
+                    refs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            rec["reference_shapes"] = refs
         if use_gpu:
             rec["summary"] = summarize(rec)       # LAST key: the tail of the line always shows every BASELINE config
         print(json.dumps(rec), flush=True)
@@ -475,7 +485,7 @@ def main():
 
 
 def summarize(rec):
-    """Compact per-config digest (<= 600 characters), emitted as the last key of the JSON line: value, roofline
+    """Compact per-config digest (<= 800 characters), emitted as the last key of the JSON line: value, roofline
     fraction, measured-over-algorithmic HBM traffic and the parity flag of the headline and of every sub-config."""
     def parity(r):
         cb = r.get("cpu_baseline") or {}
@@ -492,6 +502,12 @@ def summarize(rec):
     out = {"configs[1]": one(rec)}
     for key, sub in (rec.get("configs") or {}).items():
         out[key.replace("_one_gpu_shard", "")] = one(sub)
+    for key, sub in (rec.get("reference_shapes") or {}).items():
+        o = one(sub)
+        if "error" not in o:                      # small-codebook shapes: the HBM fraction is the one that says something
+            o["hbm_frac"] = round((sub.get("roofline") or {}).get("hbm_frac", 0.0), 3)
+            o.pop("traffic_ratio", None)
+        out[key.split("_d")[0]] = o
     return out
 
 
