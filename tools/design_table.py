@@ -16,6 +16,7 @@ names = [("encode@10000000@d300_m15_k256", "PQ encode 10 M × 300, M = 15 (confi
          ("adc_scan@100000000@d300_m15_k256", "ADC scan 100 M rows, 1 query", "hbm", 19),
          ("adc_scan@100000000@d300_m15_k256_q8", "ADC scan 100 M rows, 8 queries", "hbm", 47),
          ("encode@10000000@d128_m16_k16", "PQ encode d = 128, M = 16, K = 16 (benches/pq.rs shape)", "hbm", 528),
+         ("encode@10000000@d20_m10_k128", "PQ encode d = 20, M = 10, K = 128 (pq.rs:431-440 test shape; candidate lists)", "hbm", 90),
          ("kmeans@10000000@d300_m15_k256", "k-means iteration, 15 subquantizers, 10 M × 300", "mfma", 2 * 256 * 300),
          ("opq_train@10000000@d300_m15_k256", "OPQ training step, exact cross product", "mfma", 2 * 300 * 300 * 2 + 2 * 2 * 256 * 300),
          ("opq_train@10000000@d300_m15_k256_fastcross", "OPQ training step, float-tolerance cross product", "mfma", 2 * 300 * 300 * 2 + 2 * 2 * 256 * 300)]

@@ -15,7 +15,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-WL=${*:-"encode opq_encode reconstruct reconstruct100 encode_d768 lookup lookup100 adc_scan adc_scan8 opq_reconstruct kmeans opq_train opq_train_fast smallk"}
+WL=${*:-"encode opq_encode reconstruct reconstruct100 encode_d768 lookup lookup100 adc_scan adc_scan8 opq_reconstruct kmeans opq_train opq_train_fast smallk testshape"}
 for W in $WL; do
   case $W in
     reconstruct100) ARGS="--workload reconstruct --rows 100000000";;
@@ -23,6 +23,7 @@ for W in $WL; do
     lookup100) ARGS="--workload lookup --lookup-codes 100000000";;
     opq_train_fast) ARGS="--workload opq_train --fast-cross";;
     smallk) ARGS="--workload encode --d 128 --m 16 --k 16";;
+    testshape) ARGS="--workload encode --d 20 --m 10 --k 128";;
     *) ARGS="--workload $W";;
   esac
   CMD="$R/bench.py $ARGS --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-sub-configs"
