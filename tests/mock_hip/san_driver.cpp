@@ -42,9 +42,13 @@ static int devices_mode()
     CHECK(pqhip_ctx_create(nullptr, 0, &ctx) == PQHIP_OK && pqhip_ctx_n_devices(ctx) == 8);
     CHECK(apply_test_options(ctx));
     struct Shape { int64_t M, K, dsub, n; bool opq; };
-    for (const Shape sh : {Shape{15, 256, 20, 400003, false}, Shape{48, 256, 16, 90001, false}, Shape{15, 256, 20, 70001, true}}) {
+    // (the last two: the small-codebook kernels of round 4 -- 16x16x4 with the codebook image in LDS, and the candidate-list
+    // kernel for 2-float sub-vectors, whose tables are built on the host and replicated on every device)
+    for (const Shape sh : {Shape{15, 256, 20, 400003, false}, Shape{48, 256, 16, 90001, false}, Shape{15, 256, 20, 70001, true},
+                           Shape{16, 16, 8, 50001, false}, Shape{10, 128, 2, 60001, false}}) {
         const int64_t M = sh.M, K = sh.K, dsub = sh.dsub, d = M * dsub, n = sh.n;
-        std::vector<float> q((size_t)(M * K * dsub), 0.25f), P;
+        std::vector<float> q((size_t)(M * K * dsub)), P;
+        for (size_t i = 0; i < q.size(); ++i) q[i] = (float)((i * 2654435761ull >> 8) & 0xffff) / 65536.0f;   // distinct centroids
         if (sh.opq) { P.assign((size_t)(d * d), 0.f); for (int64_t i = 0; i < d; ++i) P[(size_t)(i * d + i)] = 1.f; }
         pqhip_codebook* cb = nullptr;
         CHECK(pqhip_codebook_create(ctx, q.data(), M, K, dsub, sh.opq ? P.data() : nullptr, &cb) == PQHIP_OK);
