@@ -66,5 +66,43 @@ def test_random_shape_matches_oracle(ra, seed):
     assert (got1.astype(np.int64) == want.astype(np.int64)).all(), ("anchor", M, K, dsub, n)
 
 
+OPQ_SHAPES = [(15, 20), (16, 16), (20, 16), (24, 16), (48, 16), (32, 16), (13, 24), (3, 5), (6, 10), (12, 4), (2, 32), (5, 7),
+              (40, 8), (9, 33), (1, 12), (56, 16)]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_opq_shape_encode_and_reconstruct_match_oracle(ra, seed):
+    """The same for `Pq` with a projection (pq.rs:276-282 encode, pq.rs:296-312 reconstruct): fused rotation + encode where
+    instantiated, rotation -> scratch -> encode elsewhere, gather inside the inverse rotation."""
+    import torch
+    import synth
+    rng = np.random.default_rng(32_000 + seed)
+    M, dsub = OPQ_SHAPES[rng.integers(len(OPQ_SHAPES))]
+    K = [16, 100, 200, 250, 256, 256, 256][rng.integers(7)]
+    n = int(rng.integers(1, 9000))
+    d = M * dsub
+    q = rng.standard_normal((M, K, dsub)).astype(np.float32)
+    P = synth.orthonormal(32_100 + seed, d)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    if n > 8 and rng.random() < 0.5:
+        x[1, rng.integers(d)] = np.nan
+        x[2] *= np.float32(1e19)
+        x[3] = 0.0
+    pad = 4 * int(rng.integers(0, 3))
+    wide = torch.zeros((n, d + pad), device="cuda")
+    wide[:, :d] = torch.from_numpy(x).cuda()
+    with np.errstate(all="ignore"):
+        want = orc.quantize_batch(q, x, projection=P, n_threads=4)
+    pq = ra.Pq(P, q)
+    got = pq.quantize_batch_device(wide[:, :d]).cpu().numpy()
+    assert got.tobytes() == want.tobytes(), (pq.last_encode_kernel(), M, K, dsub, n, pad)
+    codes = rng.integers(0, K, (n, M)).astype(np.uint8)
+    want_r = orc.reconstruct_batch(q, codes, projection=P)
+    got_r = pq.reconstruct_batch_device(torch.from_numpy(codes).cuda()).cpu().numpy()
+    assert got_r.tobytes() == want_r.tobytes(), ("reconstruct", M, K, dsub, n)
+    plain = ra.Pq(None, q)
+    assert plain.reconstruct_batch_device(torch.from_numpy(codes).cuda()).cpu().numpy().tobytes() == orc.reconstruct_batch(q, codes).tobytes()
+
+
 def test_zz_the_seeds_reach_every_kernel_family(ra):
     assert {"k_encode_small16", "k_encode_vor2", "k_encode_mfma_lds3", "k_encode_mfma"} <= SEEN, SEEN
