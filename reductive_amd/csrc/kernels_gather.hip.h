@@ -21,7 +21,10 @@ namespace pqhip {
 // G = floats fetched per codebook access inside a 16-byte output chunk: 4 when sub-vectors are made
 // of 16-byte groups, 2 or 1 when a chunk spans several sub-vectors (dsub = 2, 6, 10, .. / odd dsub);
 // the store is one dword-aligned 16-byte store either way.
-template <typename IdxT, int VEC, bool SEL = false, int G = VEC, int NE = 16>
+// CBL: the whole codebook (<= 48 KB) is copied to LDS once per workgroup and the centroids are gathered from there (round 4: small
+// codebooks -- the reference's bench shape d = 128 / K = 16 is 8 KB, its test shape d = 20 / K = 128 10 KB; a 16- or 8-byte gather per
+// output chunk through the vector memory path held those shapes at 0.63 / 0.44 of HBM).
+template <typename IdxT, int VEC, bool SEL = false, int G = VEC, int NE = 16, bool CBL = false>
 __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ codes, int64_t n,
                                                      int64_t c_rs, float* __restrict__ out,
                                                      int64_t o_rs, const float* __restrict__ cb,
@@ -55,6 +58,14 @@ __global__ __launch_bounds__(256) void k_reconstruct(const IdxT* __restrict__ co
     // SEL: per-row scale of the current and of the next block, behind the codes
     float* scl = reinterpret_cast<float*>(smem + (((size_t)ntbl * 4 + 15) & ~(size_t)15) +
                                           (((size_t)2 * ncode * sizeof(IdxT) + 15) & ~(size_t)15));  // [2][rows_per_block]
+    if constexpr (CBL) {
+        // behind everything else: the codebook image [M][K][dsub]
+        float* cbl = reinterpret_cast<float*>(smem + (((size_t)ntbl * 4 + 15) & ~(size_t)15) +
+                                              (((size_t)2 * ncode * sizeof(IdxT) + 15) & ~(size_t)15) +
+                                              (SEL ? (((size_t)2 * rows_per_block * sizeof(float) + 15) & ~(size_t)15) : 0));
+        for (int i = threadIdx.x; i < M * K * dsub; i += blockDim.x) cbl[i] = cb[i];
+        cb = cbl;                                              // (read after the first __syncthreads below)
+    }
     for (int c = threadIdx.x; c < ntbl; c += blockDim.x) {
         const int f = c * (G == 0 ? VEC : G);
         tbl[c] = (f / dsub) | ((f % dsub) << 16);

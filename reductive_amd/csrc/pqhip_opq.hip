@@ -140,9 +140,12 @@ static int32_t gather_compact(pqhip_codebook* cb, int slot, const void* d_codes,
     // (Diagnostic builds: PQHIP_DEBUG_REC_WGS overrides the per-CU count.)
     const int rec_wgs_per_cu = diag().rec_wgs;
     const int64_t nblocks = (n + rows_per_block - 1) / rows_per_block;
+    // small codebooks (plain form): the centroids are gathered from an LDS copy
+    const size_t cb_bytes = (size_t)(cb->M * cb->K * cb->dsub) * sizeof(float);
+    const bool cbl = !sel && cb_bytes <= 48 * 1024;
     const size_t lds = (((size_t)cpr * ((vec && gsz) ? 4 / gsz : 1) * sizeof(int) + 15) & ~(size_t)15) +
                        (((size_t)2 * rows_per_block * cb->M * code_bytes + 15) & ~(size_t)15) +
-                       (sel ? (size_t)2 * rows_per_block * sizeof(float) : 0);
+                       (sel ? (((size_t)2 * rows_per_block * sizeof(float) + 15) & ~(size_t)15) : 0) + (cbl ? cb_bytes : 0);
 #define LAUNCH_REC3(IDX, V, GG, NEE)                                                              \
     do {                                                                                          \
         const int per_cu = rec_wgs_per_cu ? rec_wgs_per_cu                                        \
@@ -154,7 +157,14 @@ static int32_t gather_compact(pqhip_codebook* cb, int slot, const void* d_codes,
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
                                (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
                                sel_rows, n_codes, sel_scales, s_rs);                              \
-        else                                                                                      \
+        else if (cbl) {                                                                           \
+            if (lds > 48 * 1024)                                                                  \
+                HIPCHK(hipFuncSetAttribute((const void*)k_reconstruct<IDX, V, false, GG, NEE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+            hipLaunchKernelGGL((k_reconstruct<IDX, V, false, GG, NEE, true>), dim3(grid), dim3(256), lds, st, \
+                               (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
+                               (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
+                               (const int64_t*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)1); \
+        } else                                                                                    \
             hipLaunchKernelGGL((k_reconstruct<IDX, V, false, GG, NEE>), dim3(grid), dim3(256), lds, st, \
                                (const IDX*)d_codes, n, c_rs, d_out, o_rs, cd.cb, (int)cb->M,      \
                                (int)cb->K, (int)cb->dsub, rows_per_block, inv_cpr, err,        \
