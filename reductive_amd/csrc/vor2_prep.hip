@@ -3,7 +3,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 namespace pqhip {
 namespace {
@@ -69,6 +71,71 @@ void candidates(const double* c, const double* cc, int K, double ccmax, double a
     }
 }
 
+// the region of one subquantizer; false: not eligible
+static bool build_region(const float* q, int K, int G, std::vector<uint32_t>& region)
+{
+    std::vector<double> c((size_t)2 * K), cc((size_t)K), v;
+    std::vector<int> keep;
+    double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY}, ccmax = 0.0;
+    for (int j = 0; j < K; ++j) {
+        for (int a = 0; a < 2; ++a) {
+            const double val = (double)q[2 * j + a];
+            if (!std::isfinite(val) || std::fabs(val) > 1.0995116e12) return false;     // 2^40
+            c[2 * j + a] = val;
+            lo[a] = std::min(lo[a], val);
+            hi[a] = std::max(hi[a], val);
+        }
+        cc[j] = c[2 * j] * c[2 * j] + c[2 * j + 1] * c[2 * j + 1];
+        ccmax = std::max(ccmax, cc[j]);
+    }
+    Axis fine[2], coarse[2];
+    for (int a = 0; a < 2; ++a) {
+        double s = hi[a] - lo[a];
+        const double mag = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
+        s = std::max(s, mag * 9.5367431640625e-7);                                       // 2^-20 of the magnitude
+        if (!(s >= 9.094947e-13)) s = 9.094947e-13;                                      // 2^-40
+        fine[a].G = G;
+        fine[a].lo = (float)(lo[a] - 0.5 * s);
+        fine[a].inv = (float)(G / (2.0 * s));
+        coarse[a].G = kCoarseG;
+        coarse[a].lo = (float)(lo[a] - 8.0 * s);
+        coarse[a].inv = (float)(kCoarseG / (17.0 * s));
+        if (!std::isfinite(fine[a].inv) || !std::isfinite(coarse[a].inv) || !(fine[a].inv > 0.f) || !(coarse[a].inv > 0.f)) return false;
+    }
+    region.assign((size_t)kVor2HeaderWords + (size_t)G * G + (size_t)kCoarseG * kCoarseG, 0u);
+    std::vector<uint8_t> lists;
+    region[0] = f2u(fine[0].lo); region[1] = f2u(fine[0].inv); region[2] = f2u(fine[1].lo); region[3] = f2u(fine[1].inv);
+    region[4] = f2u((float)G);
+    region[5] = f2u(coarse[0].lo); region[6] = f2u(coarse[0].inv); region[7] = f2u(coarse[1].lo); region[8] = f2u(coarse[1].inv);
+    region[9] = f2u((float)kCoarseG);
+    region[10] = (uint32_t)kVor2HeaderWords;
+    region[11] = (uint32_t)(kVor2HeaderWords + G * G);
+    region[13] = (uint32_t)G;
+    region[14] = (uint32_t)kCoarseG;
+    for (int level = 0; level < 2; ++level) {
+        const Axis* ax = level == 0 ? fine : coarse;
+        const int g = ax[0].G;
+        const uint32_t base = region[10 + level];
+        for (int i0 = 0; i0 < g; ++i0)
+            for (int i1 = 0; i1 < g; ++i1) {
+                double a0, b0, a1, b1;
+                ax[0].cell(i0, a0, b0);
+                ax[1].cell(i1, a1, b1);
+                candidates(c.data(), cc.data(), K, ccmax, a0, b0, a1, b1, keep, v);
+                if (keep.empty() || keep.size() > 256 || lists.size() + keep.size() > kMaxListBytes) return false;
+                // (count 1 .. 256 in 9 bits)
+                region[base + (uint32_t)(i0 * g + i1)] = ((uint32_t)lists.size() << 9) | (uint32_t)keep.size();
+                for (int j : keep) lists.push_back((uint8_t)j);
+                while (lists.size() % 4) lists.push_back((uint8_t)keep.back());   // whole words: the kernel reads four indices at a time
+            }
+    }
+    region[12] = (uint32_t)(region.size() * 4);
+    const size_t w0 = region.size();
+    region.resize(w0 + lists.size() / 4);
+    std::memcpy(region.data() + w0, lists.data(), lists.size());
+    return true;
+}
+
 }  // namespace
 
 bool vor2_build(const float* quantizers, int64_t M, int64_t K, Vor2Tables& out)
@@ -76,75 +143,29 @@ bool vor2_build(const float* quantizers, int64_t M, int64_t K, Vor2Tables& out)
     out.words.clear();
     out.region_off.assign(1, 0u);
     out.max_region_words = 0;
-    if (K < 1 || K > 256) return false;
+    if (K < 1 || K > 256 || M < 1) return false;
     // cells per axis of the fine grid: finer cells shorten the lists, but the tables of a workgroup's subquantizers share LDS with
     // its occupancy (d = 20, M = 10, K = 128, 10 M rows on one box: G = 16 0.94 ms, 24 0.78-0.80, 32 0.87-0.90, 48 0.97, 64 1.82)
     const int G = K >= 192 ? 32 : K >= 48 ? 24 : 16;
-    std::vector<double> c((size_t)2 * K), cc((size_t)K), v;
-    std::vector<int> keep;
+    // the subquantizers are independent: a few host threads (M = 150, K = 256: 430 ms on one thread)
+    std::vector<std::vector<uint32_t>> regions((size_t)M);
+    std::atomic<int64_t> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&] {
+        for (int64_t m = next.fetch_add(1); m < M && ok.load(std::memory_order_relaxed); m = next.fetch_add(1))
+            if (!build_region(quantizers + m * K * 2, (int)K, G, regions[(size_t)m])) ok.store(false);
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int n_threads = (int)std::min<int64_t>(std::min<int64_t>(8, hw), (M * K + 1023) / 1024);
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (!ok.load()) return false;
     for (int64_t m = 0; m < M; ++m) {
-        const float* q = quantizers + m * K * 2;
-        double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY}, ccmax = 0.0;
-        for (int j = 0; j < K; ++j) {
-            for (int a = 0; a < 2; ++a) {
-                const double val = (double)q[2 * j + a];
-                if (!std::isfinite(val) || std::fabs(val) > 1.0995116e12) return false;     // 2^40
-                c[2 * j + a] = val;
-                lo[a] = std::min(lo[a], val);
-                hi[a] = std::max(hi[a], val);
-            }
-            cc[j] = c[2 * j] * c[2 * j] + c[2 * j + 1] * c[2 * j + 1];
-            ccmax = std::max(ccmax, cc[j]);
-        }
-        Axis fine[2], coarse[2];
-        for (int a = 0; a < 2; ++a) {
-            double s = hi[a] - lo[a];
-            const double mag = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
-            s = std::max(s, mag * 9.5367431640625e-7);                                       // 2^-20 of the magnitude
-            if (!(s >= 9.094947e-13)) s = 9.094947e-13;                                      // 2^-40
-            fine[a].G = G;
-            fine[a].lo = (float)(lo[a] - 0.5 * s);
-            fine[a].inv = (float)(G / (2.0 * s));
-            coarse[a].G = kCoarseG;
-            coarse[a].lo = (float)(lo[a] - 8.0 * s);
-            coarse[a].inv = (float)(kCoarseG / (17.0 * s));
-            if (!std::isfinite(fine[a].inv) || !std::isfinite(coarse[a].inv) || !(fine[a].inv > 0.f) || !(coarse[a].inv > 0.f)) return false;
-        }
-        std::vector<uint32_t> region((size_t)kVor2HeaderWords + (size_t)G * G + (size_t)kCoarseG * kCoarseG, 0u);
-        std::vector<uint8_t> lists;
-        region[0] = f2u(fine[0].lo); region[1] = f2u(fine[0].inv); region[2] = f2u(fine[1].lo); region[3] = f2u(fine[1].inv);
-        region[4] = f2u((float)G);
-        region[5] = f2u(coarse[0].lo); region[6] = f2u(coarse[0].inv); region[7] = f2u(coarse[1].lo); region[8] = f2u(coarse[1].inv);
-        region[9] = f2u((float)kCoarseG);
-        region[10] = (uint32_t)kVor2HeaderWords;
-        region[11] = (uint32_t)(kVor2HeaderWords + G * G);
-        region[13] = (uint32_t)G;
-        region[14] = (uint32_t)kCoarseG;
-        for (int level = 0; level < 2; ++level) {
-            const Axis* ax = level == 0 ? fine : coarse;
-            const int g = ax[0].G;
-            const uint32_t base = region[10 + level];
-            for (int i0 = 0; i0 < g; ++i0)
-                for (int i1 = 0; i1 < g; ++i1) {
-                    double a0, b0, a1, b1;
-                    ax[0].cell(i0, a0, b0);
-                    ax[1].cell(i1, a1, b1);
-                    candidates(c.data(), cc.data(), (int)K, ccmax, a0, b0, a1, b1, keep, v);
-                    if (keep.empty() || keep.size() > 256 || lists.size() + keep.size() > kMaxListBytes) return false;
-                    // (count 1 .. 256 in 9 bits)
-                    region[base + (uint32_t)(i0 * g + i1)] = ((uint32_t)lists.size() << 9) | (uint32_t)keep.size();
-                    for (int j : keep) lists.push_back((uint8_t)j);
-                    while (lists.size() % 4) lists.push_back((uint8_t)keep.back());   // whole words: the kernel reads four indices at a time
-                }
-        }
-        region[12] = (uint32_t)(region.size() * 4);
-        while (lists.size() % 4) lists.push_back(0);
-        const size_t w0 = region.size();
-        region.resize(w0 + lists.size() / 4);
-        std::memcpy(region.data() + w0, lists.data(), lists.size());
-        out.words.insert(out.words.end(), region.begin(), region.end());
+        out.words.insert(out.words.end(), regions[(size_t)m].begin(), regions[(size_t)m].end());
         out.region_off.push_back((uint32_t)out.words.size());
-        out.max_region_words = std::max<uint32_t>(out.max_region_words, (uint32_t)region.size());
+        out.max_region_words = std::max<uint32_t>(out.max_region_words, (uint32_t)regions[(size_t)m].size());
     }
     return true;
 }
