@@ -104,5 +104,66 @@ def test_random_opq_shape_encode_and_reconstruct_match_oracle(ra, seed):
     assert plain.reconstruct_batch_device(torch.from_numpy(codes).cuda()).cpu().numpy().tobytes() == orc.reconstruct_batch(q, codes).tobytes()
 
 
+@pytest.mark.parametrize("seed", range(20))
+def test_random_lookup_and_adc_match_oracle(ra, seed):
+    """Row lookups with and without scales (one- and two-pass forms) and ADC tables / scans for 1 .. 9 queries, random shapes:
+    `reconstruct_batch(codes.select(rows)) * scales`, `sum_m table[m][code]` in subquantizer order."""
+    import torch
+    import synth
+    rng = np.random.default_rng(33_000 + seed)
+    dsub = [2, 3, 4, 5, 8, 10, 16, 20, 24][rng.integers(9)]
+    M = int(rng.integers(1, 33))
+    K = [2, 16, 100, 256, 256][rng.integers(5)]
+    N = int(rng.integers(1, 50_000))
+    n = int(rng.integers(1, 20_000))
+    d = M * dsub
+    q = rng.standard_normal((M, K, dsub)).astype(np.float32)
+    P = synth.orthonormal(33_100 + seed, d) if rng.random() < 0.4 else None
+    codes = rng.integers(0, K, (N, M)).astype(np.uint8)
+    rows = rng.integers(0, N, n).astype(np.int64)
+    scales = (rng.random(N).astype(np.float32) + np.float32(0.5)) if rng.random() < 0.6 else None
+    pq = ra.Pq(P, q)
+    cd = torch.from_numpy(codes).cuda()
+    want = orc.reconstruct_batch(q, codes[rows], projection=P)
+    if scales is not None:
+        want = (want * scales[rows][:, None]).astype(np.float32)
+    for two_pass in (0, 1):
+        ra.set_option("lookup_two_pass", two_pass)
+        got = pq.reconstruct_rows_device(cd, torch.from_numpy(rows).cuda(),
+                                         scales=None if scales is None else torch.from_numpy(scales).cuda()).cpu().numpy()
+        assert got.tobytes() == want.tobytes(), ("lookup", two_pass, M, K, dsub, N, n, P is not None, scales is not None)
+    ra.set_option("lookup_two_pass", 2)
+    nq = int(rng.integers(1, 10))
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    tabs = pq.adc_tables_device(torch.from_numpy(qs).cuda())
+    want_t = orc.adc_tables(q, qs, projection=P)
+    assert tabs.cpu().numpy().tobytes() == want_t.tobytes(), ("adc tables", M, K, dsub, nq)
+    dist = pq.adc_scan_device(cd, tabs).cpu().numpy()
+    assert dist.tobytes() == orc.adc_scan(want_t, codes).tobytes(), ("adc scan", M, K, dsub, N, nq)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_kmeans_iterations_match_oracle(ra, seed):
+    """kmeans_iteration for all subquantizers (kmeans.rs:289-327): assignment, row-ordered update, exact loss -- random shapes,
+    empty clusters included (more centroids than distinct rows in some seeds)."""
+    import torch
+    rng = np.random.default_rng(34_000 + seed)
+    dsub = [1, 2, 3, 4, 8, 10, 20, 33][rng.integers(8)]
+    M = int(rng.integers(1, 9))
+    K = [2, 7, 16, 64, 256, 300][rng.integers(6)]
+    n = int(rng.integers(K, 40_000))
+    x = rng.standard_normal((n, M * dsub)).astype(np.float32)
+    if rng.random() < 0.3:
+        x[: n // 2] = x[n // 2: n // 2 + n // 2][: n // 2]          # duplicated rows: exact ties between assignments
+    q0 = rng.standard_normal((M, K, dsub)).astype(np.float32)
+    if rng.random() < 0.5:
+        q0 = np.stack([x[(np.arange(K) * 31) % n, m * dsub:(m + 1) * dsub] for m in range(M)])
+    iters = int(rng.integers(1, 4))
+    want_q, want_loss = orc.kmeans_iterations(q0, x, n_iterations=iters, n_threads=4)
+    got_q, got_loss = ra.kmeans_iterations(q0, torch.from_numpy(x).cuda(), n_iterations=iters)
+    assert got_q.tobytes() == want_q.tobytes(), (M, K, dsub, n, iters)
+    assert got_loss.tobytes() == want_loss.tobytes(), (M, K, dsub, n, iters)
+
+
 def test_zz_the_seeds_reach_every_kernel_family(ra):
     assert {"k_encode_small16", "k_encode_vor2", "k_encode_mfma_lds3", "k_encode_mfma"} <= SEEN, SEEN
