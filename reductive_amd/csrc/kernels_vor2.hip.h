@@ -105,15 +105,15 @@ __global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
                 if (!in_f && in_c) ci = base_c + (int)u0 * CG + (int)u1;
                 in_any = in_f || in_c;
             }
-            const uint32_t cw = vor2_s[r0 + ci];
-            const int cnt = in_any ? (int)(cw & 511u) : 0;
-            const uint32_t* lp = vor2_s + r0 + list_w + (cw >> 11);   // (lists start on words)
+            const uint32_t cw = reinterpret_cast<const uint16_t*>(vor2_s + r0)[ci];
+            const int cnt = in_any ? (int)(cw & 15u) + 1 : 0;       // words of the list
+            const uint32_t* lp = vor2_s + r0 + list_w + (cw >> 4);    // (lists start on words)
             const f32x4* rec = rec_s + (size_t)g * a.K;
             const float xx = fadd(fmul(x0, x0), fmul(x1, x1));                 // rule 1, two elements
             float best = __builtin_inff();
             int bj = -1;
-            for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0; i += 4) {   // to the longest list of the wave, four at a time
-                const uint32_t four = (i < cnt) ? lp[i >> 2] : 0u;
+            for (int i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0; ++i) {      // to the longest list of the wave, a word (four indices) at a time
+                const uint32_t four = (i < cnt) ? lp[i] : 0u;
                 f32x4 r[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[e] = rec[(four >> (8 * e)) & 255u];

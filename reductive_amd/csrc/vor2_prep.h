@@ -31,10 +31,11 @@
 namespace pqhip {
 
 // Per subquantizer, 32-bit words: [0] lo0 [1] inv0 [2] lo1 [3] inv1 [4] G (as float) [5..8] the same for the coarse grid
-// [9] CG (float) [10] word offset of the fine cell table [11] of the coarse one [12] BYTE offset of the lists [13] G (int)
-// [14] CG (int) [15] unused; then the cell tables (u32: list offset in bytes << 9 | count) and the lists (u8 centroid
-// indices, ascending; every list starts on a word and is padded to whole words with its last index).  All offsets are
-// relative to the region's first word.
+// [9] CG (float) [10] index of the fine cell table's first 16-bit entry [11] of the coarse one's (both counted in 16-bit units
+// from the region's first word) [12] BYTE offset of the lists [13] G (int) [14] CG (int) [15] unused; then the cell tables
+// (u16: list offset in words << 4 | words - 1) and the lists (u8 centroid indices, ascending; every list starts on a word and is
+// padded to whole words with its last index; at most 16 words).  The list of a coarse cell covers the
+// part of the cell outside the fine grid only.  Offsets are relative to the region's first word.
 constexpr int kVor2HeaderWords = 16;
 
 struct Vor2Tables {

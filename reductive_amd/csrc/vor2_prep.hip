@@ -102,29 +102,58 @@ static bool build_region(const float* q, int K, int G, std::vector<uint32_t>& re
         coarse[a].inv = (float)(kCoarseG / (17.0 * s));
         if (!std::isfinite(fine[a].inv) || !std::isfinite(coarse[a].inv) || !(fine[a].inv > 0.f) || !(coarse[a].inv > 0.f)) return false;
     }
-    region.assign((size_t)kVor2HeaderWords + (size_t)G * G + (size_t)kCoarseG * kCoarseG, 0u);
+    // cell tables: 16-bit entries (list offset in words << 3 | words - 1), two per 32-bit word
+    const size_t fine_words = ((size_t)G * G + 1) / 2, coarse_words = ((size_t)kCoarseG * kCoarseG + 1) / 2;
+    region.assign((size_t)kVor2HeaderWords + fine_words + coarse_words, 0u);
+    uint16_t* cells16 = reinterpret_cast<uint16_t*>(region.data() + kVor2HeaderWords);
     std::vector<uint8_t> lists;
     region[0] = f2u(fine[0].lo); region[1] = f2u(fine[0].inv); region[2] = f2u(fine[1].lo); region[3] = f2u(fine[1].inv);
     region[4] = f2u((float)G);
     region[5] = f2u(coarse[0].lo); region[6] = f2u(coarse[0].inv); region[7] = f2u(coarse[1].lo); region[8] = f2u(coarse[1].inv);
     region[9] = f2u((float)kCoarseG);
-    region[10] = (uint32_t)kVor2HeaderWords;
-    region[11] = (uint32_t)(kVor2HeaderWords + G * G);
+    region[10] = (uint32_t)(kVor2HeaderWords * 2);                               // first 16-bit entry of the fine table
+    region[11] = (uint32_t)((kVor2HeaderWords + fine_words) * 2);                // of the coarse one
     region[13] = (uint32_t)G;
     region[14] = (uint32_t)kCoarseG;
     for (int level = 0; level < 2; ++level) {
         const Axis* ax = level == 0 ? fine : coarse;
         const int g = ax[0].G;
-        const uint32_t base = region[10 + level];
+        const uint32_t base = region[10 + level] - (uint32_t)(kVor2HeaderWords * 2);   // index into cells16
         for (int i0 = 0; i0 < g; ++i0)
             for (int i1 = 0; i1 < g; ++i1) {
                 double a0, b0, a1, b1;
                 ax[0].cell(i0, a0, b0);
                 ax[1].cell(i1, a1, b1);
-                candidates(c.data(), cc.data(), K, ccmax, a0, b0, a1, b1, keep, v);
-                if (keep.empty() || keep.size() > 256 || lists.size() + keep.size() > kMaxListBytes) return false;
-                // (count 1 .. 256 in 9 bits)
-                region[base + (uint32_t)(i0 * g + i1)] = ((uint32_t)lists.size() << 9) | (uint32_t)keep.size();
+                if (level == 0) {
+                    candidates(c.data(), cc.data(), K, ccmax, a0, b0, a1, b1, keep, v);
+                } else {
+                    // A coarse cell serves only the points the fine grid does not take: its list covers the cell minus the fine
+                    // grid's extent (shrunk by 2^-10 of a fine cell: a point that close to the edge may land on either side) --
+                    // up to four rectangles; a coarse cell inside the fine grid is never looked up.
+                    double f0a, f0b, f1a, f1b, t;
+                    fine[0].cell(0, f0a, t); fine[0].cell(G - 1, t, f0b);
+                    fine[1].cell(0, f1a, t); fine[1].cell(G - 1, t, f1b);
+                    const double m0 = 2.0 / 1024 / (double)fine[0].inv, m1 = 2.0 / 1024 / (double)fine[1].inv;
+                    f0a += m0; f0b -= m0; f1a += m1; f1b -= m1;          // cell() widened them; shrink past the true edge
+                    std::vector<int> all, part;
+                    auto add = [&](double r0a, double r0b, double r1a, double r1b) {
+                        if (!(r0a < r0b) || !(r1a < r1b)) return;
+                        candidates(c.data(), cc.data(), K, ccmax, r0a, r0b, r1a, r1b, part, v);
+                        all.insert(all.end(), part.begin(), part.end());
+                    };
+                    add(a0, std::min(b0, f0a), a1, b1);                                          // left of the fine grid
+                    add(std::max(a0, f0b), b0, a1, b1);                                          // right
+                    add(std::max(a0, f0a), std::min(b0, f0b), a1, std::min(b1, f1a));            // below
+                    add(std::max(a0, f0a), std::min(b0, f0b), std::max(a1, f1b), b1);            // above
+                    std::sort(all.begin(), all.end());
+                    all.erase(std::unique(all.begin(), all.end()), all.end());
+                    if (all.empty()) all.push_back(0);                                           // unreachable cell
+                    keep = all;
+                }
+                // a list is 1 .. 16 words (64 candidates) at a word offset below 4,096: anything else is not eligible
+                const size_t nwords = (keep.size() + 3) / 4;
+                if (keep.empty() || nwords > 16 || lists.size() / 4 >= 4096 || lists.size() + keep.size() > kMaxListBytes) return false;
+                cells16[base + (uint32_t)(i0 * g + i1)] = (uint16_t)((lists.size() / 4) << 4 | (nwords - 1));
                 for (int j : keep) lists.push_back((uint8_t)j);
                 while (lists.size() % 4) lists.push_back((uint8_t)keep.back());   // whole words: the kernel reads four indices at a time
             }
@@ -145,8 +174,9 @@ bool vor2_build(const float* quantizers, int64_t M, int64_t K, Vor2Tables& out)
     out.max_region_words = 0;
     if (K < 1 || K > 256 || M < 1) return false;
     // cells per axis of the fine grid: finer cells shorten the lists, but the tables of a workgroup's subquantizers share LDS with
-    // its occupancy (d = 20, M = 10, K = 128, 10 M rows on one box: G = 16 0.94 ms, 24 0.78-0.80, 32 0.87-0.90, 48 0.97, 64 1.82)
-    const int G = K >= 192 ? 32 : K >= 48 ? 24 : 16;
+    // its occupancy (d = 20, M = 10, 10 M rows on one box, 16-bit cell entries: K = 128: G = 16 0.87 ms, 20 0.79, 24 0.735, 28 0.78,
+    // 32 0.74, 40 0.90, 48 0.88; K = 256: G = 24 1.06, 32 1.14, 40 1.01; with 32-bit entries G = 24 took 0.78 and 32 0.87-0.90)
+    const int G = K >= 48 ? 24 : 16;
     // the subquantizers are independent: a few host threads (M = 150, K = 256: 430 ms on one thread)
     std::vector<std::vector<uint32_t>> regions((size_t)M);
     std::atomic<int64_t> next{0};
