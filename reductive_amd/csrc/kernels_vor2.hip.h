@@ -2,7 +2,7 @@
 // are evaluated (round 4; the tables and the argument why the first minimum is always among them: vor2_prep.h).
 //
 // One LANE owns one row and walks the subquantizers of the workgroup's group (blockIdx.y); the group's tables -- grid
-// parameters, cell -> (list offset, count) words, the lists of centroid indices -- its centroids and their norms live in LDS.
+// parameters, 16-bit cell entries (list offset, length in words), the lists of centroid indices -- its centroids and their norms live in LDS.
 // Per (row, m): the cell from two subtract-multiply pairs (exactly the operations the tables were built for; the grid parameters
 // come through the scalar path), one LDS word for the cell, then the list four indices (one word) at a time: four independent
 // 16-byte records {c0, c1, ||c||^2}, and per candidate, in ascending centroid order, the distance by the literal
