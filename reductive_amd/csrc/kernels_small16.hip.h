@@ -1,4 +1,4 @@
-// kernels_small16.hip.h -- PQ encode for small codebooks (K <= 32) and sub-vectors of 4 / 8 floats on
+// kernels_small16.hip.h -- PQ encode for small codebooks (K <= 32) and sub-vectors of 4 / 8 / 16 floats on
 // v_mfma_f32_16x16x4_f32 (round 4).
 //
 // Why.  k_encode_smallk (kernels_smallk.hip.h) keeps the centroids on the scalar path: every k-step of a sub-vector waits for one
@@ -56,11 +56,17 @@ __device__ __forceinline__ void gather_pairs(float v, f32x2& e02, f32x2& o13)
 template <int T, int DSUB, bool FULL>
 __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKArgs a)
 {
-    static_assert((T == 1 || T == 2) && (DSUB == 4 || DSUB == 8), "no such instantiation");
+    static_assert((T == 1 || T == 2) && (DSUB == 4 || DSUB == 8 || DSUB == 16), "no such instantiation");
     constexpr int KP = 16 * T;
     constexpr int S = DSUB / 4;               // 16-byte pieces = matrix instructions per chain
-    constexpr int SVL = 2 / S;                // sub-vectors a lane holds per row block and stage (two pieces)
-    constexpr int NSV = 32 / DSUB;            // sub-vectors per stage (32 floats of a row): 4 SVL
+    // A lane holds PPL pieces of a row per row block and stage -- whole sub-vectors, so that the norms are lane-local -- and a
+    // tile is RBN row blocks: 64 rows x 32 floats per stage up to 8-float sub-vectors, 32 rows x 64 floats for 16-float ones
+    // (the same 32 registers per stage either way).
+    constexpr int PPL = small16_pieces_per_lane(DSUB);
+    constexpr int RBN = small16_tile_rows(DSUB) / 16;
+    constexpr int TR = 16 * RBN;              // rows per tile
+    constexpr int SVL = PPL / S;              // sub-vectors a lane holds per row block and stage
+    constexpr int NSV = 4 * SVL;              // sub-vectors per stage (16 PPL floats of a row)
     extern __shared__ __attribute__((aligned(16))) float small16_dyn_s[];
     float* const afrag_s = small16_dyn_s;                                  // [M][DSUB][KP]
     float* const cc_s = small16_dyn_s + (size_t)a.M * DSUB * KP;           // [M][KP]
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
     // block (an atomic instruction touches 512 contiguous bytes) and the four row blocks' slots of one lane group sit 32 banks
     // apart for the read-back (first layout, [row block][i16][q]: 2-way bank conflicts in every atomic and read -- the LDS pipe was
     // busy 92 % of the kernel, 5/7 of it in conflict cycles, tools/sq_counters.sh)
-    constexpr int RBS = 80, PS = 4 * RBS;
+    constexpr int RBS = 80, PS = RBN * RBS;
     __shared__ __attribute__((aligned(16))) long long slot_s[4][2][PS];
 
     const int lane = threadIdx.x & 63;
@@ -80,38 +86,38 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
     for (int i = threadIdx.x; i < a.M * KP; i += 256) cc_s[i] = a.cc[(int64_t)(i / KP) * a.k_pad + (i % KP)];
     __syncthreads();
 
-    const int64_t n_tiles = (a.n + 63) / 64;
+    const int64_t n_tiles = (a.n + TR - 1) / TR;
     const int64_t tile_begin = ((int64_t)blockIdx.x * 4 + wave) * a.tiles_per_wave;
     if (tile_begin >= n_tiles) return;
     const int ntile = (int)((n_tiles - tile_begin < a.tiles_per_wave) ? n_tiles - tile_begin : a.tiles_per_wave);
     const int NP = (a.M * DSUB) / 4;          // 16-byte pieces per row
-    const int NST = (NP + 7) / 8;             // stages per tile
+    const int NST = (NP + 4 * PPL - 1) / (4 * PPL);   // stages per tile
 
-    // ---- x stage: raw[rb][j] = floats [32 st + 8 q + 4 j, + 4) of row 16 rb + i16 of the tile: the four lane groups read one
-    // 128-byte line of a row with two instructions, an instruction touches 16 lines (one row per lane -- 64 lines per instruction --
-    // measured 15 % slower in this kernel).  Rows past the end are clamped to the last row, pieces past the end of the row to its
-    // last piece: loaded, never used.
-    unsigned voff[4];
+    // ---- x stage: raw[rb][j] = floats [16 PPL st + 4 PPL q + 4 j, + 4) of row 16 rb + i16 of the tile: the four lane groups read
+    // whole 128-byte lines of a row with PPL instructions, an instruction touches 16 lines (one row per lane -- 64 lines per
+    // instruction -- measured 15 % slower in this kernel).  Rows past the end are clamped to the last row, pieces past the end of
+    // the row to its last piece: loaded, never used.
+    unsigned voff[RBN];
     auto tile_offsets = [&](int64_t row0) {
-        const int left = (int)((a.n - row0 < 64) ? a.n - row0 : 64);        // wave-uniform
+        const int left = (int)((a.n - row0 < TR) ? a.n - row0 : TR);        // wave-uniform
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
+        for (int rb = 0; rb < RBN; ++rb) {
             const int r = (16 * rb + i16 < left) ? 16 * rb + i16 : left - 1;
             voff[rb] = (unsigned)((int64_t)r * a.x_rs * 4);
         }
     };
-    auto issue = [&](f32x4 (&raw)[4][2], int64_t row0, int st) {
+    auto issue = [&](f32x4 (&raw)[RBN][PPL], int64_t row0, int st) {
         const char* base = reinterpret_cast<const char*>(a.x + row0 * a.x_rs);
-        unsigned pb[2];                       // byte offset of the lane's pieces inside the row
+        unsigned pb[PPL];                     // byte offset of the lane's pieces inside the row
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pc = 8 * st + 2 * q + j;
+        for (int j = 0; j < PPL; ++j) {
+            const int pc = 4 * PPL * st + PPL * q + j;
             pb[j] = 16u * (unsigned)((pc < NP) ? pc : NP - 1);
         }
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < RBN; ++rb)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) raw[rb][j] = *reinterpret_cast<const f32x4*>(base + (voff[rb] + pb[j]));
+            for (int j = 0; j < PPL; ++j) raw[rb][j] = *reinterpret_cast<const f32x4*>(base + (voff[rb] + pb[j]));
     };
 
     // index halves of the keys (one register each, never rewritten)
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
             asm volatile("" : "+v"(lo[t][v]));
         }
     long long* const my_slot = &slot_s[wave][0][0] + lane;                 // + PS par + RBS rb
-    const long long* const row_slots = &slot_s[wave][0][0] + RBS * q + i16;   // lane L = row L = (rb = q, i16): + 16 q' for q' = 0..3
+    const long long* const row_slots = &slot_s[wave][0][0] + RBS * (q < RBN ? q : 0) + i16;   // lane L = row L = (rb = q, i16): + 16 q' for q' = 0..3
 
     unsigned long long flagged = 0;           // wave-uniform: tiles with rows for the exact path
     unsigned cw = 0;                          // code bytes of row `lane`, four subquantizers at a time
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
         const float best = __int_as_float(hf);
         const bool odd = !(best >= 0.f && best < __builtin_inff());
         const int code = odd ? 0xff : lf;
-        const int left = (int)((a.n - trow0 < 64) ? a.n - trow0 : 64);      // wave-uniform
+        const int left = (int)((a.n - trow0 < TR) ? a.n - trow0 : TR);      // wave-uniform
         const bool valid = lane < left;
         if (__builtin_amdgcn_ballot_w64(odd && valid)) flagged |= 1ull << ti;
         const int sh = 8 * (m & 3);           // wave-uniform
@@ -182,16 +188,24 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
     // Lane group q holds the sub-vectors q SVL .. q SVL + SVL - 1 of the stage for the rows 16 rb + i16.
     float af[T][S];
     f32x4 c4[T];
-    auto stage = [&](f32x4 (&cur)[4][2], int64_t row0, int st, int ti) {
+    auto stage = [&](f32x4 (&cur)[RBN][PPL], int64_t row0, int st, int ti) {
         // rule 1, lane-local (the lane holds whole sub-vectors), and a gather over the lane groups:
         // xe[rb][l] = (||sv 0 SVL + l||^2, ||sv 2 SVL + l||^2), xo[rb][l] = (sv 1 SVL + l, sv 3 SVL + l) of row 16 rb + i16
-        f32x2 xe[4][SVL], xo[4][SVL];
+        f32x2 xe[RBN][SVL], xo[RBN][SVL];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < RBN; ++rb)
 #pragma unroll
             for (int l = 0; l < SVL; ++l) {
                 float xx;
-                if constexpr (DSUB == 8) {    // p[i] = x_i^2; ((p0 + p4) + (p1 + p5)) + (p2 + p6)) + (p3 + p7)
+                if constexpr (DSUB == 16) {   // p[i] = x_i^2 + x_(8+i)^2 (two chunks of eight), then the same fold
+                    const f32x4 v0 = cur[rb][0], v1 = cur[rb][1], v2 = cur[rb][2], v3 = cur[rb][3];
+                    const f32x2 a01 = {v0[0], v0[1]}, a23 = {v0[2], v0[3]}, a45 = {v1[0], v1[1]}, a67 = {v1[2], v1[3]};
+                    const f32x2 b01 = {v2[0], v2[1]}, b23 = {v2[2], v2[3]}, b45 = {v3[0], v3[1]}, b67 = {v3[2], v3[3]};
+                    const f32x2 p01 = pk_add(pk_mul(a01, a01), pk_mul(b01, b01)), p23 = pk_add(pk_mul(a23, a23), pk_mul(b23, b23));
+                    const f32x2 p45 = pk_add(pk_mul(a45, a45), pk_mul(b45, b45)), p67 = pk_add(pk_mul(a67, a67), pk_mul(b67, b67));
+                    const f32x2 u01 = pk_add(p01, p45), u23 = pk_add(p23, p67);
+                    xx = fadd(fadd(fadd(u01[0], u01[1]), u23[0]), u23[1]);
+                } else if constexpr (DSUB == 8) {    // p[i] = x_i^2; ((p0 + p4) + (p1 + p5)) + (p2 + p6)) + (p3 + p7)
                     const f32x4 v0 = cur[rb][0], v1 = cur[rb][1];
                     const f32x2 a01 = {v0[0], v0[1]}, a23 = {v0[2], v0[3]}, a45 = {v1[0], v1[1]}, a67 = {v1[2], v1[3]};
                     const f32x2 u01 = pk_add(pk_mul(a01, a01), pk_mul(a45, a45)), u23 = pk_add(pk_mul(a23, a23), pk_mul(a67, a67));
@@ -205,11 +219,11 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
                 gather_pairs(xx, xe[rb][l], xo[rb][l]);
             }
         // B operands, in place: bo[rb][j][r] = x[row 16 rb + i16][32 st + 8 r + 4 j + q] (piece j of lane group r)
-        float bo[4][2][4];
+        float bo[RBN][PPL][4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < RBN; ++rb)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < PPL; ++j) {
                 const f32x4 v = cur[rb][j];
                 const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
                 const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
@@ -226,15 +240,15 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
             if (FULL || m < a.M) {            // wave-uniform (false only past the end of the row in its last stage)
                 const int parity = c & 1;     // NSV is even: the parity of m
                 const int r = c / SVL, l = c % SVL;   // the lane group that fetched the sub-vector, and which of its sub-vectors
-                f32x4 acc[4][T];
+                f32x4 acc[RBN][T];
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
+                for (int rb = 0; rb < RBN; ++rb)
 #pragma unroll
                     for (int t = 0; t < T; ++t) acc[rb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < S; ++s)
 #pragma unroll
-                    for (int rb = 0; rb < 4; ++rb)
+                    for (int rb = 0; rb < RBN; ++rb)
 #pragma unroll
                         for (int t = 0; t < T; ++t)
                             acc[rb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bo[rb][l * S + s][r], acc[rb][t], 0, 0, 0);
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
                 // the previous sub-vector's code while the chains run
                 if (m > 0) finalize(m - 1, parity ^ 1, row0, ti);
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
+                for (int rb = 0; rb < RBN; ++rb) {
                     long long* slot = my_slot + PS * parity + RBS * rb;
                     const f32x2 xp = (r & 1) ? xo[rb][l] : xe[rb][l];     // the norm is its low (r < 2) or high half
 #pragma unroll
@@ -278,8 +292,8 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
 
     // ---- the wave's stages, two register sets: while one is encoded the other is on its way from HBM.  After the last stage the
     // same stage is requested again (a load behind a branch makes the compiler wait for it at the join).
-    f32x4 raw_a[4][2], raw_b[4][2];
-    int64_t row0 = tile_begin * 64;
+    f32x4 raw_a[RBN][PPL], raw_b[RBN][PPL];
+    int64_t row0 = tile_begin * TR;
     int tile = 0, st = 0;
     const int total = ntile * NST;
     int64_t n_row0 = row0;
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
             if (++n_st == NST) {
                 n_st = 0;
                 ++n_tile;
-                n_row0 += 64;
+                n_row0 += TR;
                 tile_offsets(n_row0);
             }
         }
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
     while (flagged) {                                                       // wave-uniform
         const int ti = __builtin_ctzll(flagged);
         flagged &= flagged - 1;
-        const int64_t trow0 = (tile_begin + ti) * 64;
+        const int64_t trow0 = (tile_begin + ti) * TR;
         const bool valid = trow0 + lane < a.n;
         const volatile uint8_t* o = a.out + (trow0 + lane) * a.o_rs;
         for (int m = 0; m < a.M; ++m) {

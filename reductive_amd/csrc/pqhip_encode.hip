@@ -188,7 +188,8 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         a.M = (int)cb->M; a.K = (int)cb->K; a.k_pad = cb->k_pad;
         // consecutive 64-row tiles per wave: the codebook image is staged once per workgroup, so as many as leave about
         // eight rounds of workgroups for the launch
-        const int64_t n_tiles = (n + 63) / 64;
+        const int64_t tile_rows = small16_tile_rows((int)cb->dsub);
+        const int64_t n_tiles = (n + tile_rows - 1) / tile_rows;
         const int64_t wg_slots = (int64_t)cb->ctx->devs[slot]->n_cus * 4 * 8;
         a.word_stores = (o_rs % 4 == 0 && ((uintptr_t)d_codes & 3) == 0) ? 1 : 0;
         a.tiles_per_wave = (int)std::max<int64_t>(1, std::min<int64_t>(kSmall16TilesMax, n_tiles / (4 * wg_slots)));

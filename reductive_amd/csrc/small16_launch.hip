@@ -8,7 +8,7 @@ bool launch_small16(int KP, int dsub, const SmallKArgs& a, dim3 grid, size_t lds
 {
 #define PQHIP_CASE(T, D)                                                                          \
     if (KP == 16 * T && dsub == D) {                                                              \
-        if (a.M % (32 / D) == 0) {                                                                \
+        if (a.M % (16 * small16_pieces_per_lane(D) / D) == 0) {                                                                \
             if (lds > 48 * 1024 &&                                                                \
                 hipFuncSetAttribute((const void*)k_encode_small16<T, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) \
                 return false;                                                                     \
@@ -21,8 +21,8 @@ bool launch_small16(int KP, int dsub, const SmallKArgs& a, dim3 grid, size_t lds
         }                                                                                         \
         return true;                                                                              \
     }
-    PQHIP_CASE(1, 4) PQHIP_CASE(1, 8)
-    PQHIP_CASE(2, 4) PQHIP_CASE(2, 8)
+    PQHIP_CASE(1, 4) PQHIP_CASE(1, 8) PQHIP_CASE(1, 16)
+    PQHIP_CASE(2, 4) PQHIP_CASE(2, 8) PQHIP_CASE(2, 16)
 #undef PQHIP_CASE
     return false;
 }
