@@ -1,4 +1,4 @@
-// kernels_small16.hip.h -- PQ encode for small codebooks (K <= 32) and sub-vectors of 4 / 8 / 16 floats on
+// kernels_small16.hip.h -- PQ encode for small codebooks (K <= 32) and sub-vectors of 4 / 8 / 16 / 32 floats on
 // v_mfma_f32_16x16x4_f32 (round 4).
 //
 // Why.  k_encode_smallk (kernels_smallk.hip.h) keeps the centroids on the scalar path: every k-step of a sub-vector waits for one
@@ -56,12 +56,12 @@ __device__ __forceinline__ void gather_pairs(float v, f32x2& e02, f32x2& o13)
 template <int T, int DSUB, bool FULL>
 __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKArgs a)
 {
-    static_assert((T == 1 || T == 2) && (DSUB == 4 || DSUB == 8 || DSUB == 16), "no such instantiation");
+    static_assert((T == 1 || T == 2) && (DSUB == 4 || DSUB == 8 || DSUB == 16 || DSUB == 32), "no such instantiation");
     constexpr int KP = 16 * T;
     constexpr int S = DSUB / 4;               // 16-byte pieces = matrix instructions per chain
     // A lane holds PPL pieces of a row per row block and stage -- whole sub-vectors, so that the norms are lane-local -- and a
-    // tile is RBN row blocks: 64 rows x 32 floats per stage up to 8-float sub-vectors, 32 rows x 64 floats for 16-float ones
-    // (the same 32 registers per stage either way).
+    // tile is RBN row blocks: 64 rows x 32 floats per stage up to 8-float sub-vectors, 32 rows x 64 floats for 16-float ones,
+    // 16 rows x 128 floats for 32-float ones (the same 32 registers per stage in every case).
     constexpr int PPL = small16_pieces_per_lane(DSUB);
     constexpr int RBN = small16_tile_rows(DSUB) / 16;
     constexpr int TR = 16 * RBN;              // rows per tile
@@ -197,18 +197,22 @@ __global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKAr
 #pragma unroll
             for (int l = 0; l < SVL; ++l) {
                 float xx;
-                if constexpr (DSUB == 16) {   // p[i] = x_i^2 + x_(8+i)^2 (two chunks of eight), then the same fold
-                    const f32x4 v0 = cur[rb][0], v1 = cur[rb][1], v2 = cur[rb][2], v3 = cur[rb][3];
-                    const f32x2 a01 = {v0[0], v0[1]}, a23 = {v0[2], v0[3]}, a45 = {v1[0], v1[1]}, a67 = {v1[2], v1[3]};
-                    const f32x2 b01 = {v2[0], v2[1]}, b23 = {v2[2], v2[3]}, b45 = {v3[0], v3[1]}, b67 = {v3[2], v3[3]};
-                    const f32x2 p01 = pk_add(pk_mul(a01, a01), pk_mul(b01, b01)), p23 = pk_add(pk_mul(a23, a23), pk_mul(b23, b23));
-                    const f32x2 p45 = pk_add(pk_mul(a45, a45), pk_mul(b45, b45)), p67 = pk_add(pk_mul(a67, a67), pk_mul(b67, b67));
-                    const f32x2 u01 = pk_add(p01, p45), u23 = pk_add(p23, p67);
-                    xx = fadd(fadd(fadd(u01[0], u01[1]), u23[0]), u23[1]);
-                } else if constexpr (DSUB == 8) {    // p[i] = x_i^2; ((p0 + p4) + (p1 + p5)) + (p2 + p6)) + (p3 + p7)
-                    const f32x4 v0 = cur[rb][0], v1 = cur[rb][1];
-                    const f32x2 a01 = {v0[0], v0[1]}, a23 = {v0[2], v0[3]}, a45 = {v1[0], v1[1]}, a67 = {v1[2], v1[3]};
-                    const f32x2 u01 = pk_add(pk_mul(a01, a01), pk_mul(a45, a45)), u23 = pk_add(pk_mul(a23, a23), pk_mul(a67, a67));
+                if constexpr (DSUB >= 8) {
+                    // rule 1: p[i] = (((x_i^2 + x_(8+i)^2) + x_(16+i)^2) + ..) over the chunks of eight, then
+                    // (((p0 + p4) + (p1 + p5)) + (p2 + p6)) + (p3 + p7); pieces 2 c and 2 c + 1 of the lane are chunk c
+                    constexpr int NCH = DSUB / 8;
+                    f32x2 pp[4];              // (p0, p1), (p2, p3), (p4, p5), (p6, p7)
+#pragma unroll
+                    for (int pi = 0; pi < 4; ++pi) {
+#pragma unroll
+                        for (int ch = 0; ch < NCH; ++ch) {
+                            const f32x4 v = cur[rb][2 * ch + (pi >> 1)];
+                            const f32x2 e = {v[2 * (pi & 1)], v[2 * (pi & 1) + 1]};
+                            const f32x2 sq = pk_mul(e, e);
+                            pp[pi] = ch == 0 ? sq : pk_add(pp[pi], sq);
+                        }
+                    }
+                    const f32x2 u01 = pk_add(pp[0], pp[2]), u23 = pk_add(pp[1], pp[3]);
                     xx = fadd(fadd(fadd(u01[0], u01[1]), u23[0]), u23[1]);
                 } else {                      // four tail elements: ((x0^2 + x1^2) + x2^2) + x3^2
                     const f32x4 v = cur[rb][l];

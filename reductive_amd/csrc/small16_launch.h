@@ -1,4 +1,4 @@
-// small16_launch.h -- host-side launcher of k_encode_small16 (K <= 32, sub-vectors of 4 / 8 / 16 floats, 16-byte aligned rows);
+// small16_launch.h -- host-side launcher of k_encode_small16 (K <= 32, sub-vectors of 4 / 8 / 16 / 32 floats, 16-byte aligned rows);
 // the instantiations live in their own translation unit, small16_launch.hip.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -6,10 +6,10 @@
 
 namespace pqhip {
 constexpr int kSmall16TilesMax = 64;   // tiles per wave: one bit each in the kernel's exact-path mask
-inline bool small16_has(int KP, int dsub) { return (KP == 16 || KP == 32) && (dsub == 4 || dsub == 8 || dsub == 16); }
+inline bool small16_has(int KP, int dsub) { return (KP == 16 || KP == 32) && (dsub == 4 || dsub == 8 || dsub == 16 || dsub == 32); }
 // rows of a wave's tile and 16-byte pieces a lane holds per row block and stage (kernels_small16.hip.h)
-constexpr int small16_tile_rows(int dsub) { return dsub == 16 ? 32 : 64; }
-constexpr int small16_pieces_per_lane(int dsub) { return dsub == 16 ? 4 : 2; }
+constexpr int small16_tile_rows(int dsub) { return dsub == 32 ? 16 : dsub == 16 ? 32 : 64; }
+constexpr int small16_pieces_per_lane(int dsub) { return dsub == 32 ? 8 : dsub == 16 ? 4 : 2; }
 // dynamic LDS of a workgroup: the transposed codebook image and the centroid norms
 inline size_t small16_lds_bytes(int M, int dsub, int KP) { return ((size_t)M * dsub * KP + (size_t)M * KP) * sizeof(float); }
 // false: no instantiation for (KP, dsub)
