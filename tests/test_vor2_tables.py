@@ -131,6 +131,33 @@ def test_points_on_cell_boundaries_and_on_centroids(ra):
     check(ra, q2, x2, min_fast=1.0)
 
 
+@pytest.mark.parametrize("K,scale", [(128, 1.0), (16, 1.0), (256, 1.0), (128, 1e-6), (128, 4e5)])
+def test_points_on_bisectors_of_centroid_pairs(ra, K, scale):
+    """Where list membership decides: points ON the perpendicular bisector of two centroids (the two distances agree to the
+    last bits, either may win after rounding, and the tie rule picks the lower index) and a few ulps to either side of it, for
+    pairs that are Voronoi neighbours and pairs that are not, at positions spread over both grids."""
+    M = 2
+    rng = np.random.default_rng(9350 + K)
+    q = (rng.standard_normal((M, K, 2)) * scale).astype(np.float32)
+    n = 150_000
+    x = np.zeros((n, 2 * M), dtype=np.float32)
+    for m in range(M):
+        i = rng.integers(0, K, n)
+        j = (i + 1 + rng.integers(0, max(K - 1, 1), n)) % K
+        a, b = q[m, i].astype(np.float64), q[m, j].astype(np.float64)
+        mid, dirv = (a + b) / 2, (b - a)[:, ::-1] * np.array([1.0, -1.0])
+        t = rng.standard_normal(n)[:, None] * rng.choice([0.0, 0.1, 1.0, 5.0], n)[:, None]
+        p = (mid + t * dirv).astype(np.float32)
+        k = rng.integers(-3, 4, n)                                            # 0 .. 3 ulps off the bisector, either side
+        step = np.where(k >= 0, np.float32(np.inf), np.float32(-np.inf)).astype(np.float32)
+        for _ in range(3):
+            move = np.abs(k) > 0
+            p[move, 0] = np.nextafter(p[move, 0], step[move])
+            k = k - np.sign(k)
+        x[:, 2 * m:2 * m + 2] = p
+    check(ra, q, x)
+
+
 @pytest.mark.parametrize("kind", ["identical", "collinear", "outlier", "tiny", "large", "two_clusters", "lattice"])
 def test_adversarial_codebooks(ra, kind):
     M, K = 2, 64
