@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
             const float t0 = fmul(fsub(x0, __uint_as_float(hdr[0])), __uint_as_float(hdr[1]));
             const float t1 = fmul(fsub(x1, __uint_as_float(hdr[2])), __uint_as_float(hdr[3]));
             const float gf = __uint_as_float(hdr[4]);
-            const int base_f = (int)hdr[10], G = (int)hdr[13];
+            const int base_f = (int)hdr[10], G = (int)hdr[13], sub_base = (int)hdr[15];
             const uint32_t list_w = hdr[12] >> 2;
             const bool in_f = (t0 >= 0.f) & (t0 < gf) & (t1 >= 0.f) & (t1 < gf);
             bool in_any = in_f;
@@ -105,7 +105,15 @@ __global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
                 if (!in_f && in_c) ci = base_c + (int)u0 * CG + (int)u1;
                 in_any = in_f || in_c;
             }
-            const uint32_t cw = reinterpret_cast<const uint16_t*>(vor2_s + r0)[ci];
+            const uint16_t* cells = reinterpret_cast<const uint16_t*>(vor2_s + r0);
+            uint32_t cw = cells[ci];
+            const bool split = in_f && (cw & 15u) == 15u;              // a dense fine cell: one of its four half cells
+            if (__builtin_amdgcn_ballot_w64(split) != 0) {
+                const float f0 = fsub(t0, (float)(int)t0), f1 = fsub(t1, (float)(int)t1);    // exact
+                const int si = sub_base + 4 * (int)(cw >> 4) + 2 * (f0 >= 0.5f ? 1 : 0) + (f1 >= 0.5f ? 1 : 0);
+                const uint32_t cw2 = cells[split ? si : 0];
+                if (split) cw = cw2;
+            }
             const int cnt = in_any ? (int)(cw & 15u) + 1 : 0;       // words of the list
             const uint32_t* lp = vor2_s + r0 + list_w + (cw >> 4);    // (lists start on words)
             const f32x4* rec = rec_s + (size_t)g * a.K;

@@ -31,11 +31,13 @@
 namespace pqhip {
 
 // Per subquantizer, 32-bit words: [0] lo0 [1] inv0 [2] lo1 [3] inv1 [4] G (as float) [5..8] the same for the coarse grid
-// [9] CG (float) [10] index of the fine cell table's first 16-bit entry [11] of the coarse one's (both counted in 16-bit units
-// from the region's first word) [12] BYTE offset of the lists [13] G (int) [14] CG (int) [15] unused; then the cell tables
-// (u16: list offset in words << 4 | words - 1) and the lists (u8 centroid indices, ascending; every list starts on a word and is
-// padded to whole words with its last index; at most 16 words).  The list of a coarse cell covers the
-// part of the cell outside the fine grid only.  Offsets are relative to the region's first word.
+// [9] CG (float) [10] index of the fine cell table's first 16-bit entry [11] of the coarse one's [15] of the sub-cell table's
+// (all counted in 16-bit units from the region's first word) [12] BYTE offset of the lists [13] G (int) [14] CG (int); then the
+// cell tables and the lists.  A cell entry is u16: list offset in words << 4 | words - 1 (lists: u8 centroid indices, ascending;
+// every list starts on a word and is padded to whole words with its last index; at most 16 words).  A FINE cell entry whose
+// length field is 15 is subdivided: bits 15..4 number a group of four entries in the sub-cell table, one per half cell
+// (2 [t0 - floor(t0) >= 0.5] + [t1 - floor(t1) >= 0.5]), each a plain entry (up to 16 words; plain FINE entries: 15).  The list of a coarse cell
+// covers the part of the cell outside the fine grid only.  Offsets are relative to the region's first word.
 constexpr int kVor2HeaderWords = 16;
 
 struct Vor2Tables {

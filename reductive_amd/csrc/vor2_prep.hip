@@ -24,6 +24,13 @@ struct Axis {
         a = (double)lo + (i - 1.0 / 1024) * w;
         b = (double)lo + (i + 1 + 1.0 / 1024) * w;
     }
+    // half h of cell i (the kernel: fl(t - floor(t)) >= 0.5, exact on the computed t), widened
+    void half(int i, int h, double& a, double& b) const
+    {
+        const double w = 1.0 / (double)inv;
+        a = (double)lo + (i + 0.5 * h - 1.0 / 1024) * w;
+        b = (double)lo + (i + 0.5 * (h + 1) + 1.0 / 1024) * w;
+    }
 };
 
 inline uint32_t f2u(float f)
@@ -107,6 +114,16 @@ static bool build_region(const float* q, int K, int G, std::vector<uint32_t>& re
     region.assign((size_t)kVor2HeaderWords + fine_words + coarse_words, 0u);
     uint16_t* cells16 = reinterpret_cast<uint16_t*>(region.data() + kVor2HeaderWords);
     std::vector<uint8_t> lists;
+    std::vector<uint16_t> sub16;              // entries of the subdivided fine cells, four per cell
+    // appends a list; the entry (list offset in words << 4 | words - 1), or 0xffff when it does not fit the format
+    auto emit = [&](const std::vector<int>& l, size_t max_words) -> uint16_t {
+        const size_t nwords = (l.size() + 3) / 4;
+        if (l.empty() || nwords > max_words || lists.size() / 4 >= 4096 || lists.size() + l.size() > kMaxListBytes) return 0xffff;
+        const uint16_t e = (uint16_t)((lists.size() / 4) << 4 | (nwords - 1));
+        for (int j : l) lists.push_back((uint8_t)j);
+        while (lists.size() % 4) lists.push_back((uint8_t)l.back());       // whole words: the kernel reads four indices at a time
+        return e;
+    };
     region[0] = f2u(fine[0].lo); region[1] = f2u(fine[0].inv); region[2] = f2u(fine[1].lo); region[3] = f2u(fine[1].inv);
     region[4] = f2u((float)G);
     region[5] = f2u(coarse[0].lo); region[6] = f2u(coarse[0].inv); region[7] = f2u(coarse[1].lo); region[8] = f2u(coarse[1].inv);
@@ -150,13 +167,42 @@ static bool build_region(const float* q, int K, int G, std::vector<uint32_t>& re
                     if (all.empty()) all.push_back(0);                                           // unreachable cell
                     keep = all;
                 }
-                // a list is 1 .. 16 words (64 candidates) at a word offset below 4,096: anything else is not eligible
-                const size_t nwords = (keep.size() + 3) / 4;
-                if (keep.empty() || nwords > 16 || lists.size() / 4 >= 4096 || lists.size() + keep.size() > kMaxListBytes) return false;
-                cells16[base + (uint32_t)(i0 * g + i1)] = (uint16_t)((lists.size() / 4) << 4 | (nwords - 1));
-                for (int j : keep) lists.push_back((uint8_t)j);
-                while (lists.size() % 4) lists.push_back((uint8_t)keep.back());   // whole words: the kernel reads four indices at a time
+                // A list is 1 .. 16 words (64 candidates) at a word offset below 4,096 (fine cells: 15 words -- 15 in the length
+                // field marks a subdivided cell); anything else is not eligible.  A fine cell with more than two words of
+                // candidates is split into 2 x 2 half cells when that shortens its longest list: the wave walks to the longest
+                // list among its 64 rows, so the dense cells set the pace.
+                uint16_t entry = 0xffff;
+                if (level == 0 && keep.size() > 8 && sub16.size() / 4 < 4096) {
+                    std::vector<int> part[4];
+                    size_t longest = 0;
+                    for (int h = 0; h < 4; ++h) {
+                        double s0a, s0b, s1a, s1b;
+                        ax[0].half(i0, h >> 1, s0a, s0b);
+                        ax[1].half(i1, h & 1, s1a, s1b);
+                        candidates(c.data(), cc.data(), K, ccmax, s0a, s0b, s1a, s1b, part[h], v);
+                        longest = std::max(longest, part[h].size());
+                    }
+                    if (longest < keep.size() || keep.size() > 60) {       // (a 16-word list cannot be a plain fine entry)
+                        uint16_t se[4];
+                        bool ok4 = true;
+                        for (int h = 0; h < 4; ++h) { se[h] = emit(part[h], 16); ok4 = ok4 && se[h] != 0xffff; }
+                        if (!ok4) return false;
+                        entry = (uint16_t)((sub16.size() / 4) << 4 | 15u);
+                        for (int h = 0; h < 4; ++h) sub16.push_back(se[h]);
+                    }
+                }
+                if (entry == 0xffff) entry = emit(keep, level == 0 ? 15 : 16);
+                if (entry == 0xffff) return false;
+                cells16[base + (uint32_t)(i0 * g + i1)] = entry;
             }
+    }
+    // the sub-cell entries behind the two cell tables
+    region[15] = (uint32_t)(region.size() * 2);
+    {
+        while (sub16.size() % 2) sub16.push_back(0);
+        const size_t w = region.size();
+        region.resize(w + sub16.size() / 2);
+        if (!sub16.empty()) std::memcpy(region.data() + w, sub16.data(), sub16.size() * 2);
     }
     region[12] = (uint32_t)(region.size() * 4);
     const size_t w0 = region.size();

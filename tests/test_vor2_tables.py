@@ -42,7 +42,14 @@ def walk(words, off, q, x):
         s0 = np.where(in_f, t0, np.where(in_c, u0, 0)).astype(np.int64)
         s1 = np.where(in_f, t1, np.where(in_c, u1, 0)).astype(np.int64)
         ci = np.where(in_f, int(r[10]) + s0 * G + s1, int(r[11]) + s0 * CG + s1)
-        cw = r.view(np.uint16)[ci].astype(np.int64)           # 16-bit cell entries: list offset in words << 4 | words - 1
+        c16 = r.view(np.uint16)
+        cw = c16[ci].astype(np.int64)                         # 16-bit cell entries: list offset in words << 4 | words - 1
+        split = in_f & ((cw & 15) == 15)                      # a subdivided fine cell: the entry of the point's half cell
+        with np.errstate(all="ignore"):
+            f0 = (t0 - np.floor(np.where(in_f, t0, 0)).astype(f32)).astype(f32)
+            f1 = (t1 - np.floor(np.where(in_f, t1, 0)).astype(f32)).astype(f32)
+        si = int(r[15]) + 4 * (cw >> 4) + 2 * (f0 >= np.float32(0.5)) + (f1 >= np.float32(0.5))
+        cw = np.where(split, c16[np.where(split, si, 0)].astype(np.int64), cw)
         ok = in_f | in_c
         nwords = np.where(ok, (cw & 15) + 1, 0)
         lofs = cw >> 4
