@@ -52,9 +52,11 @@ __device__ __forceinline__ void gather_pairs(float v, f32x2& e02, f32x2& o13)
     o13 = (f32x2){__uint_as_float(d[0]), __uint_as_float(d[1])};
 }
 
-// FULL: M is a multiple of the sub-vectors per stage (no stage runs past the end of a row)
+// FULL: M is a multiple of the sub-vectors per stage (no stage runs past the end of a row).
+// Waves per SIMD: three (156 registers at 8 floats; a fourth spills 36 of them: 1.8 instead of 1.2 ms), four for 16-float sub-vectors
+// (128 registers: d = 768 / M = 48 6.40 -> 6.08 ms per 10 M rows), three again for 32-float ones (four: 7.38 -> 8.24 ms), two for K > 16.
 template <int T, int DSUB, bool FULL>
-__global__ __launch_bounds__(256, T == 1 ? 3 : 2) void k_encode_small16(SmallKArgs a)
+__global__ __launch_bounds__(256, T == 1 ? (DSUB == 16 ? 4 : 3) : 2) void k_encode_small16(SmallKArgs a)
 {
     static_assert((T == 1 || T == 2) && (DSUB == 4 || DSUB == 8 || DSUB == 16 || DSUB == 32), "no such instantiation");
     constexpr int KP = 16 * T;
