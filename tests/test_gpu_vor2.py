@@ -74,6 +74,28 @@ def test_ties_duplicates_and_uniform_data(ra):
     assert got.tobytes() == want.tobytes()
 
 
+def test_opq_rotation_then_candidate_lists(ra):
+    """`Pq` with a projection and 2-float sub-vectors: the rotated rows (scratch chunks of the two-kernel OPQ path) go through
+    the candidate-list kernel; codes equal the oracle's (pq.rs:276-282)."""
+    import torch
+    M, K, n = 12, 64, 50_001
+    d = 2 * M
+    rng = np.random.default_rng(9750)
+    q = rng.standard_normal((M, K, 2)).astype(np.float32)
+    P = synth.orthonormal(9751, d)
+    x = synth.normalish(9752, (n, d))
+    x[7] *= np.float32(300.0)
+    x[8, 3] = np.nan
+    pq = ra.Pq(P, q)
+    with np.errstate(all="ignore"):
+        want = orc.quantize_batch(q, x, projection=P, n_threads=8)
+    ra.launch_log(reset=True)
+    got = pq.quantize_batch_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    torch.cuda.synchronize()
+    assert "k_encode_vor2" in ra.launch_log(reset=True)
+    assert got.tobytes() == want.tobytes()
+
+
 def test_five_million_rows_against_the_mfma_kernel(ra):
     """Size-independent check: the candidate-list kernel and the kernel that evaluates every centroid (variant 4) are two
     independent implementations of cluster_assignment; all n x M codes must be equal."""
