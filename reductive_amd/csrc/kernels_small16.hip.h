@@ -12,7 +12,9 @@
 // built to issue as few of either as the arithmetic allows:
 //   * a lane fetches 32 bytes of a row per row block and stage -- lane (i16, q): floats [32 st + 8 q, + 8) of row 16 rb + i16,
 //     so the four lane groups read one 128-byte line and an instruction touches 16 lines; the next stage's loads (64 rows x 32
-//     floats) are in flight while the current one is encoded (two register sets, the loop body is instantiated for both);
+//     floats) are in flight while the current one is encoded (two register sets, the loop body is instantiated for both).
+//     (That is the geometry up to 8-float sub-vectors; 16-float ones take 32-row tiles and 64 bytes per lane, row block and
+//     stage, 32-float ones 16-row tiles and 128 bytes: always whole sub-vectors per lane and 32 registers per stage);
 //   * ||x_m||^2 (rule 1) is lane-local -- the lane holds whole sub-vectors: 9 instructions for 64 (row, sub-vector) pairs --
 //     and one gather over the lane groups (v_permlane16_swap + 2 v_permlane32_swap) hands a lane the norms of the stage's
 //     sub-vectors for its row;
@@ -33,7 +35,8 @@
 //     encode_rows_slow_v.  (The other kernels test the norm against kBigNorm instead: that keeps NaNs out of the keys.  Here a
 //     NaN or an overflow anywhere in a row's candidates makes its minimum key negative, NaN or +Inf -- a negative NaN is a
 //     negative integer, a positive one the largest -- so testing the minimum alone is enough.)
-// Four waves per SIMD; a wave runs `tiles_per_wave` consecutive 64-row tiles.  Requires 16-byte aligned rows (host dispatch);
+// Three waves per SIMD (four for 16-float sub-vectors, two for K > 16); a wave runs `tiles_per_wave` consecutive tiles.
+// Requires 16-byte aligned rows (host dispatch);
 // codes are bit-identical to k_encode_smallk and the oracle (tests/test_gpu_smallk.py).
 #pragma once
 #include "small16_launch.h"
