@@ -277,7 +277,7 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float 
  *   7  two subquantizers per matrix tile (K <= 16)           auto for 2 floats, and 4 floats from 48 subquantizers on
  *   8  OPQ only: rotation + encode in one kernel             auto where instantiated (opq_fused2_launch.h)
  *   9  MFMA 16x16x4, LDS-atomic argmin, four waves per SIMD  auto for K > 128 and sub-vectors of 12 .. 24 floats
- *  10  MFMA 16x16x4 for small codebooks (K <= 32, 4 / 8 / 16 / 32 floats, u8 codes, 16-byte aligned rows)   auto wherever it fits
+ *  10  MFMA 16x16x4 for small codebooks (K <= 32, 4 / 8 / 12 / 16 / 20 / 24 / 32 floats, u8 codes, 16-byte aligned rows)   auto wherever it fits
  *  11  2-float sub-vectors, K <= 256: per-cell candidate lists (Pq handles with finite, in-range centroids)   auto for K > 16
  *   (3 and 5 named kernels that rounds 1-2 shipped; PQHIP_EINVAL since round 4)                                  */
 int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);

@@ -1,4 +1,4 @@
-// kernels_small16.hip.h -- PQ encode for small codebooks (K <= 32) and sub-vectors of 4 / 8 / 16 / 32 floats on
+// kernels_small16.hip.h -- PQ encode for small codebooks (K <= 32) and sub-vectors of 4 / 8 / 12 / 16 / 20 / 24 / 32 floats on
 // v_mfma_f32_16x16x4_f32 (round 4).
 //
 // Why.  k_encode_smallk (kernels_smallk.hip.h) keeps the centroids on the scalar path: every k-step of a sub-vector waits for one
@@ -13,8 +13,8 @@
 //   * a lane fetches 32 bytes of a row per row block and stage -- lane (i16, q): floats [32 st + 8 q, + 8) of row 16 rb + i16,
 //     so the four lane groups read one 128-byte line and an instruction touches 16 lines; the next stage's loads (64 rows x 32
 //     floats) are in flight while the current one is encoded (two register sets, the loop body is instantiated for both).
-//     (That is the geometry up to 8-float sub-vectors; 16-float ones take 32-row tiles and 64 bytes per lane, row block and
-//     stage, 32-float ones 16-row tiles and 128 bytes: always whole sub-vectors per lane and 32 registers per stage);
+//     (That is the geometry up to 8-float sub-vectors; 12- to 20-float ones take 32-row tiles and one whole sub-vector per lane,
+//     row block and stage, 24- and 32-float ones 16-row tiles: always whole sub-vectors per lane, 24 to 40 registers per stage);
 //   * ||x_m||^2 (rule 1) is lane-local -- the lane holds whole sub-vectors: 9 instructions for 64 (row, sub-vector) pairs --
 //     and one gather over the lane groups (v_permlane16_swap + 2 v_permlane32_swap) hands a lane the norms of the stage's
 //     sub-vectors for its row;
@@ -56,12 +56,13 @@ __device__ __forceinline__ void gather_pairs(float v, f32x2& e02, f32x2& o13)
 }
 
 // FULL: M is a multiple of the sub-vectors per stage (no stage runs past the end of a row).
-// Waves per SIMD: three (156 registers at 8 floats; a fourth spills 36 of them: 1.8 instead of 1.2 ms), four for 16-float sub-vectors
-// (128 registers: d = 768 / M = 48 6.40 -> 6.08 ms per 10 M rows), three again for 32-float ones (four: 7.38 -> 8.24 ms), two for K > 16.
+// Waves per SIMD: three (156 registers at 8 floats; a fourth spills 36 of them: 1.8 instead of 1.2 ms), four for 12-, 16- and 24-float
+// sub-vectors (<= 128 registers: d = 768 / M = 48 6.40 -> 6.08 ms per 10 M rows, d = 768 / M = 32 6.70 -> 5.96), three again for 20- and
+// 32-float ones (32 floats with four: 7.38 -> 8.24 ms), two for K > 16.
 template <int T, int DSUB, bool FULL>
-__global__ __launch_bounds__(256, T == 1 ? (DSUB == 16 ? 4 : 3) : 2) void k_encode_small16(SmallKArgs a)
+__global__ __launch_bounds__(256, T == 1 ? ((DSUB == 16 || DSUB == 12 || DSUB == 24) ? 4 : 3) : 2) void k_encode_small16(SmallKArgs a)
 {
-    static_assert((T == 1 || T == 2) && (DSUB == 4 || DSUB == 8 || DSUB == 16 || DSUB == 32), "no such instantiation");
+    static_assert((T == 1 || T == 2) && small16_has(16 * T, DSUB), "no such instantiation");
     constexpr int KP = 16 * T;
     constexpr int S = DSUB / 4;               // 16-byte pieces = matrix instructions per chain
     // A lane holds PPL pieces of a row per row block and stage -- whole sub-vectors, so that the norms are lane-local -- and a
@@ -203,8 +204,9 @@ __global__ __launch_bounds__(256, T == 1 ? (DSUB == 16 ? 4 : 3) : 2) void k_enco
             for (int l = 0; l < SVL; ++l) {
                 float xx;
                 if constexpr (DSUB >= 8) {
-                    // rule 1: p[i] = (((x_i^2 + x_(8+i)^2) + x_(16+i)^2) + ..) over the chunks of eight, then
-                    // (((p0 + p4) + (p1 + p5)) + (p2 + p6)) + (p3 + p7); pieces 2 c and 2 c + 1 of the lane are chunk c
+                    // rule 1: p[i] = (((x_i^2 + x_(8+i)^2) + x_(16+i)^2) + ..) over the full chunks of eight, then
+                    // s = (((p0 + p4) + (p1 + p5)) + (p2 + p6)) + (p3 + p7), then the (four) tail elements one by one;
+                    // pieces 2 c and 2 c + 1 of the lane are chunk c, the tail is the last piece
                     constexpr int NCH = DSUB / 8;
                     f32x2 pp[4];              // (p0, p1), (p2, p3), (p4, p5), (p6, p7)
 #pragma unroll
@@ -219,6 +221,12 @@ __global__ __launch_bounds__(256, T == 1 ? (DSUB == 16 ? 4 : 3) : 2) void k_enco
                     }
                     const f32x2 u01 = pk_add(pp[0], pp[2]), u23 = pk_add(pp[1], pp[3]);
                     xx = fadd(fadd(fadd(u01[0], u01[1]), u23[0]), u23[1]);
+                    if constexpr (DSUB % 8 != 0) {
+                        const f32x4 v = cur[rb][2 * NCH];
+                        const f32x2 a01 = {v[0], v[1]}, a23 = {v[2], v[3]};
+                        const f32x2 s01 = pk_mul(a01, a01), s23 = pk_mul(a23, a23);
+                        xx = fadd(fadd(fadd(fadd(xx, s01[0]), s01[1]), s23[0]), s23[1]);
+                    }
                 } else {                      // four tail elements: ((x0^2 + x1^2) + x2^2) + x3^2
                     const f32x4 v = cur[rb][l];
                     const f32x2 a01 = {v[0], v[1]}, a23 = {v[2], v[3]};

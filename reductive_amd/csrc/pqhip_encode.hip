@@ -173,7 +173,7 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
         return PQHIP_OK;
     }
     if (cb->variant == 7) return PQHIP_EUNSUPPORTED;
-    // K <= 32, sub-vectors of 4 / 8 / 16 / 32 floats and 16-byte aligned rows: the 16x16x4 kernel with the
+    // K <= 32, sub-vectors of 4 / 8 / 12 / 16 / 20 / 24 / 32 floats and 16-byte aligned rows: the 16x16x4 kernel with the
     // transposed codebook image in LDS (kernels_small16.hip.h).  Variant 10 forces it.
     const bool s16_fits = cb->KP != 0 && small16_has(cb->KP, (int)cb->dsub) && code_bytes == 1 && cb->norms_ok && bad_flag == nullptr &&
                           x_rs % 4 == 0 && ((uintptr_t)d_x & 15) == 0 && small16_lds_bytes((int)cb->M, (int)cb->dsub, cb->KP) <= 96 * 1024;
@@ -182,7 +182,9 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     // 1.29e9 / 0.85e9, d=64 M=8 1.41e10 / 1.10e10, K=32: d=128 M=16 5.2e9 / 4.5e9, d=300 M=75 1.49e9 / 1.25e9 -- except 4-float
     // sub-vectors from 48 subquantizers on at K <= 16, which stay with the pair kernel above (d=300 M=75: 1.95e9 / 2.07e9).
     // 16- and 32-float sub-vectors (tools/small16_sweep16.sh): d=768 M=48 K=16 1.48e9 / 1.11e9, d=128 M=8 8.0e9 / 6.3e9,
-    // d=1024 M=64 1.09e9 / 0.85e9, d=1024 M=32 1.25e9 / 1.05e9, d=768 M=24 1.44e9 / 1.37e9, K=32: d=128 M=8 5.8e9 / 5.5e9.
+    // d=1024 M=64 1.09e9 / 0.85e9, d=1024 M=32 1.25e9 / 1.05e9, d=768 M=24 1.44e9 / 1.37e9, K=32: d=128 M=8 5.8e9 / 5.5e9;
+    // 12 / 20 / 24 floats: d=300 M=25 3.0e9 / 2.25e9, d=300 M=15 K=16 (the headline shape with 4-bit codes) 3.2e9 / 2.7e9,
+    // d=768 M=32 1.47e9 / 1.15e9, d=300 M=15 K=32 2.57e9 / 2.57e9.
     if ((cb->variant == 10 || cb->variant == 0) && s16_fits) {
         SmallKArgs a;
         a.x = d_x; a.n = n; a.x_rs = x_rs; a.out = (uint8_t*)d_codes; a.o_rs = o_rs;

@@ -21,8 +21,8 @@ bool launch_small16(int KP, int dsub, const SmallKArgs& a, dim3 grid, size_t lds
         }                                                                                         \
         return true;                                                                              \
     }
-    PQHIP_CASE(1, 4) PQHIP_CASE(1, 8) PQHIP_CASE(1, 16) PQHIP_CASE(1, 32)
-    PQHIP_CASE(2, 4) PQHIP_CASE(2, 8) PQHIP_CASE(2, 16) PQHIP_CASE(2, 32)
+    PQHIP_CASE(1, 4) PQHIP_CASE(1, 8) PQHIP_CASE(1, 12) PQHIP_CASE(1, 16) PQHIP_CASE(1, 20) PQHIP_CASE(1, 24) PQHIP_CASE(1, 32)
+    PQHIP_CASE(2, 4) PQHIP_CASE(2, 8) PQHIP_CASE(2, 12) PQHIP_CASE(2, 16) PQHIP_CASE(2, 20) PQHIP_CASE(2, 24) PQHIP_CASE(2, 32)
 #undef PQHIP_CASE
     return false;
 }

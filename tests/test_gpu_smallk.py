@@ -40,7 +40,7 @@ def test_every_instantiation_matches_oracle(ra, K, dsub):
     # auto: K <= 16 with sub-vectors of 2 floats (or 4 floats and >= 48 subquantizers) -> the pair kernel; other K <= 16, dsub <= 8 -> this one
     # K <= 32 with 4-, 8- or 16-float sub-vectors -> the 16x16x4 kernel; other K <= 16, dsub <= 8 -> the scalar-path kernel
     pair = K <= 16 and (dsub == 2 or (dsub == 4 and M >= 48))
-    s16 = K <= 32 and dsub in (4, 8, 16, 32) and not pair
+    s16 = K <= 32 and dsub in (4, 8, 12, 16, 20, 24, 32) and not pair
     assert (auto.last_encode_kernel() == "k_encode_pair16") == pair
     assert (auto.last_encode_kernel() == "k_encode_small16") == s16
     assert (auto.last_encode_kernel() == "k_encode_smallk") == (K <= 16 and dsub <= 8 and not pair and not s16)
@@ -162,7 +162,9 @@ def test_pair_kernel_is_refused_outside_its_shapes(ra):
                                         (5, 30, 4, 777), (14, 16, 8, 6400), (16, 1, 8, 64), (32, 16, 4, 263_000), (1, 3, 4, 100),
                                         (37, 16, 8, 5000), (75, 32, 4, 2000), (48, 16, 16, 20001), (3, 16, 16, 3000), (8, 32, 16, 9999),
                                         (1, 16, 16, 1), (5, 30, 16, 777), (13, 7, 16, 33), (32, 16, 32, 30001), (3, 16, 32, 2000),
-                                        (8, 32, 32, 5001), (1, 9, 32, 17), (6, 16, 32, 16)])
+                                        (8, 32, 32, 5001), (1, 9, 32, 17), (6, 16, 32, 16), (15, 16, 20, 70001), (15, 32, 20, 5001),
+                                        (7, 16, 12, 3333), (3, 9, 24, 999), (25, 16, 12, 40000), (10, 16, 24, 20001), (1, 16, 20, 1),
+                                        (4, 16, 20, 33)])
 def test_small16_kernel(ra, M, K, dsub, n):
     """kernels_small16.hip.h (variant 10 / auto for K <= 16 with 8-float sub-vectors): one and two centroid tiles, K < 16
     (padding centroids), rows that end inside a 32-float stage, M not a multiple of 4 (byte tail of the code word), ragged
@@ -198,7 +200,7 @@ def test_small16_kernel(ra, M, K, dsub, n):
 
 def test_small16_kernel_is_refused_outside_its_shapes(ra):
     import torch
-    for shape, cols in (((4, 40, 8), 32), ((4, 16, 24), 96), ((4, 16, 12), 48)):   # K > 32; 24- and 12-float sub-vectors
+    for shape, cols in (((4, 40, 8), 32), ((4, 16, 10), 40), ((4, 16, 6), 24)):   # K > 32; 10- and 6-float sub-vectors
         pq = ra.Pq(None, synth.normalish(8990, shape))
         pq.set_encode_variant(10)
         with pytest.raises(Exception):
