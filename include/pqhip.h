@@ -278,7 +278,8 @@ int32_t pqhip_at_dot_b_f32_dev(pqhip_ctx *ctx, int32_t device_slot, const float 
  *   8  OPQ only: rotation + encode in one kernel             auto where instantiated (opq_fused2_launch.h)
  *   9  MFMA 16x16x4, LDS-atomic argmin, four waves per SIMD  auto for K > 128 and sub-vectors of 12 .. 24 floats
  *  10  MFMA 16x16x4 for small codebooks (K <= 32, 4 / 8 / 12 / 16 / 20 / 24 / 32 floats, u8 codes, 16-byte aligned rows)   auto wherever it fits
- *  11  2-float sub-vectors, K <= 256: per-cell candidate lists (Pq handles with finite, in-range centroids)   auto for K > 16
+ *  11  1- and 2-float sub-vectors, K <= 256: per-cell candidate lists (Pq handles with finite, in-range centroids)
+ *      auto for K > 16, and for every K at 1 float
  *   (3 and 5 named kernels that rounds 1-2 shipped; PQHIP_EINVAL since round 4)                                  */
 int32_t pqhip_set_encode_variant(pqhip_codebook *cb, int32_t variant);
 /* process-wide: the P-block rotation kernel where both exist (16-byte aligned rows, d % 4 == 0):
@@ -306,13 +307,13 @@ int32_t pqhip_ctx_set_option(pqhip_ctx *ctx, const char *name, int64_t value);
  * it), pqhip_launch_log_reset() clears it.  bench.py reports roofline.kernel from it.                            */
 const char *pqhip_launch_log(void);
 void pqhip_launch_log_reset(void);
-/* Host only (no GPU needed): the candidate tables k_encode_vor2 uses for a codebook of 2-float sub-vectors, as built at
+/* Host only (no GPU needed): the candidate tables k_encode_vor2 uses for a codebook of 1- or 2-float sub-vectors, as built at
  * codebook creation (layout and the argument why the winner is always on a cell's list: reductive_amd/csrc/vor2_prep.h).
- * quantizers [M][K][2].  *n_words receives the number of 32-bit words; words_out (capacity words_cap, may be NULL to ask
+ * quantizers [M][K][dsub], dsub 1 or 2.  *n_words receives the number of 32-bit words; words_out (capacity words_cap, may be NULL to ask
  * for the size) the regions back to back, region_off_out [M + 1] their word offsets.  PQHIP_EUNSUPPORTED when the codebook
  * is not eligible (K > 256, non-finite or extreme centroids).  The CPU test-suite checks the tables against the oracle. */
-int32_t pqhip_vor2_tables_host(const float *quantizers, int64_t M, int64_t K, uint32_t *words_out, int64_t words_cap,
-                               uint32_t *region_off_out, int64_t *n_words);
+int32_t pqhip_vor2_tables_host(const float *quantizers, int64_t M, int64_t K, int64_t dsub, uint32_t *words_out,
+                               int64_t words_cap, uint32_t *region_off_out, int64_t *n_words);
 /* name of the encode kernel the last device call on this codebook launched ("" if none)        */
 const char *pqhip_last_encode_kernel(const pqhip_codebook *cb);
 

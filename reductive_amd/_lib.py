@@ -127,7 +127,7 @@ def lib():
     L.pqhip_launch_log_reset.restype = None
     L.pqhip_launch_log_reset.argtypes = []
     L.pqhip_vor2_tables_host.restype = i32
-    L.pqhip_vor2_tables_host.argtypes = [vp, i64, i64, vp, i64, vp, ctypes.POINTER(i64)]
+    L.pqhip_vor2_tables_host.argtypes = [vp, i64, i64, i64, vp, i64, vp, ctypes.POINTER(i64)]
     L.pqhip_selftest_mfma_chain.restype = i32
     L.pqhip_selftest_mfma_chain.argtypes = [vp, i32, i32, i32, ctypes.c_uint64,
                                             ctypes.POINTER(i64)]

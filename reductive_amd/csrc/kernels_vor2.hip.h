@@ -1,4 +1,4 @@
-// kernels_vor2.hip.h -- PQ encode for 2-float sub-vectors (K <= 256): only the centroids that can win in the point's grid cell
+// kernels_vor2.hip.h -- PQ encode for 2-float (and 1-float) sub-vectors (K <= 256): only the centroids that can win in the point's grid cell
 // are evaluated (round 4; the tables and the argument why the first minimum is always among them: vor2_prep.h).
 //
 // One LANE owns one row and walks the subquantizers of the workgroup's group (blockIdx.y); the group's tables -- grid
@@ -28,6 +28,7 @@ struct Vor2Args {
     const uint32_t* tab;  // the regions of vor2_prep.h, back to back
     const uint32_t* off;  // [M + 1] word offsets into tab
     int M, K, k_pad;
+    int dsub;             // 1 or 2 floats per sub-vector (1: the second coordinate is 0 everywhere)
     int mg;               // subquantizers per workgroup (blockIdx.y selects the group)
     int rows_per_thread;
 };
@@ -51,21 +52,42 @@ __global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
     for (uint32_t i = threadIdx.x; i < nw_raw; i += 256) vor2_s[i] = a.tab[w0 + i];
     for (int i = threadIdx.x; i < nm * a.K; i += 256) {
         const int g = i / a.K, j = i - g * a.K;
-        const float* c = a.cb + ((int64_t)(m0 + g) * a.K + j) * 2;
-        rec_s[i] = (f32x4){c[0], c[1], a.cc[(int64_t)(m0 + g) * a.k_pad + j], 0.f};
+        const float* c = a.cb + ((int64_t)(m0 + g) * a.K + j) * a.dsub;
+        rec_s[i] = (f32x4){c[0], a.dsub == 2 ? c[1] : 0.f, a.cc[(int64_t)(m0 + g) * a.k_pad + j], 0.f};
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
+    const bool word_stores = (a.o_rs % 4 == 0) && (m0 % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 3) == 0);
     const int64_t block_row0 = (int64_t)blockIdx.x * 256 * a.rows_per_thread;
     // the row's floats of the group: requested one row ahead
     float xn[2 * MG];
+    const int nfl = a.dsub * nm;                                   // floats of the group per row
+    // 16-byte loads when the group's floats start on 16 bytes in every row (row stride, base and first column)
+    const bool vec4 = (a.x_rs % 4 == 0) && ((a.dsub * m0) % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     auto fetch = [&](int it) {
         int64_t row = block_row0 + (int64_t)it * 256 + threadIdx.x;
         if (row >= a.n) row = a.n - 1;
-        const float* xr = a.x + row * a.x_rs + 2 * m0;
+        const float* xr = a.x + row * a.x_rs + a.dsub * m0;
+        if (vec4) {                                                // (wave-uniform; whole pieces: the row has them, x_rs >= d)
 #pragma unroll
-        for (int e = 0; e < 2 * MG; ++e) xn[e] = xr[(e < 2 * nm) ? e : 0];
+            for (int e = 0; e < 2 * MG; e += 4) {
+                if (e < nfl) {
+                    const int64_t left = a.x_rs - (int64_t)a.dsub * m0 - e;   // floats of the row from here on: >= 1
+                    if (left >= 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + e);
+                        xn[e] = v[0]; xn[e + 1] = v[1]; xn[e + 2] = v[2]; xn[e + 3] = v[3];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xn[e + k] = (k < left) ? xr[e + k] : 0.f;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 2 * MG; ++e)
+                if (e < nfl) xn[e] = xr[e];
+        }
     };
     fetch(0);
     for (int it = 0; it < a.rows_per_thread; ++it) {
@@ -78,6 +100,7 @@ __global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
         for (int e = 0; e < 2 * MG; ++e) xs[e] = xn[e];
         fetch((it + 1 < a.rows_per_thread) ? it + 1 : it);
         uint8_t* orow = a.out + row * a.o_rs + m0;
+        unsigned codes_lo = 0, codes_hi = 0, bad = 0;                // the group's code bytes of this row; bit g of bad: exact path
 #pragma unroll
         for (int g = 0; g < MG; ++g) {
             if (g >= nm) break;                                    // wave-uniform
@@ -85,23 +108,23 @@ __global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
             const uint32_t hoff = off_c[m0 + g];
             const vor2_cptr hdr = tab_c + hoff;
             const uint32_t r0 = hoff - w0;                         // the region's first word in LDS
-            const float x0 = xs[2 * g], x1 = xs[2 * g + 1];
+            const float x0 = a.dsub == 2 ? xs[2 * g] : xs[g], x1 = a.dsub == 2 ? xs[2 * g + 1] : 0.f;
             // cell: fine grid, else coarse grid, else the exact path.  (Every header word is fetched as a scalar BEFORE the
             // lane-dependent choice: a load of a selected address would be a vector load whose latency nothing hides.)
             const float t0 = fmul(fsub(x0, __uint_as_float(hdr[0])), __uint_as_float(hdr[1]));
             const float t1 = fmul(fsub(x1, __uint_as_float(hdr[2])), __uint_as_float(hdr[3]));
-            const float gf = __uint_as_float(hdr[4]);
+            const float gf0 = __uint_as_float(hdr[4]), gf1 = __uint_as_float(hdr[16]);
             const int base_f = (int)hdr[10], G = (int)hdr[13], sub_base = (int)hdr[15];
             const uint32_t list_w = hdr[12] >> 2;
-            const bool in_f = (t0 >= 0.f) & (t0 < gf) & (t1 >= 0.f) & (t1 < gf);
+            const bool in_f = (t0 >= 0.f) & (t0 < gf0) & (t1 >= 0.f) & (t1 < gf1);
             bool in_any = in_f;
             int ci = base_f + (in_f ? (int)t0 * G + (int)t1 : 0);
             if (__builtin_amdgcn_ballot_w64(!in_f) != 0) {                      // some lane of the wave is outside the fine grid
                 const float u0 = fmul(fsub(x0, __uint_as_float(hdr[5])), __uint_as_float(hdr[6]));
                 const float u1 = fmul(fsub(x1, __uint_as_float(hdr[7])), __uint_as_float(hdr[8]));
-                const float cgf = __uint_as_float(hdr[9]);
+                const float cgf0 = __uint_as_float(hdr[9]), cgf1 = __uint_as_float(hdr[17]);
                 const int base_c = (int)hdr[11], CG = (int)hdr[14];
-                const bool in_c = (u0 >= 0.f) & (u0 < cgf) & (u1 >= 0.f) & (u1 < cgf);
+                const bool in_c = (u0 >= 0.f) & (u0 < cgf0) & (u1 >= 0.f) & (u1 < cgf1);
                 if (!in_f && in_c) ci = base_c + (int)u0 * CG + (int)u1;
                 in_any = in_f || in_c;
             }
@@ -137,11 +160,25 @@ __global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
             }
             if (cnt == 0) bj = -1;                                             // outside both grids / NaN / Inf: the exact path
             const unsigned long long need = __builtin_amdgcn_ballot_w64(valid && bj < 0);
-            if (valid && bj >= 0) orow[g] = (uint8_t)bj;
+            if (bj < 0) bad |= 1u << g;
+            else if (g < 4) codes_lo |= (unsigned)bj << (8 * g);
+            else codes_hi |= (unsigned)bj << (8 * (g - 4));
             if (need) {                                                       // wave-uniform
                 const unsigned l32 = (unsigned)need, h32 = (unsigned)(need >> 32);
-                if (l32) encode_rows_slow_v<uint8_t>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, 2, a.k_pad, 0, m0 + g, wave_row0, l32);
-                if (h32) encode_rows_slow_v<uint8_t>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, 2, a.k_pad, 0, m0 + g, wave_row0 + 32, h32);
+                if (l32) encode_rows_slow_v<uint8_t>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, 0, m0 + g, wave_row0, l32);
+                if (h32) encode_rows_slow_v<uint8_t>(a.x, a.x_rs, a.out, a.o_rs, a.cb, a.cc, a.K, a.dsub, a.k_pad, 0, m0 + g, wave_row0 + 32, h32);
+            }
+        }
+        // the row's codes of the group: whole words where the code matrix allows it (one byte store per (row, m) is 64 cache
+        // lines per instruction and a partial write each), bytes otherwise and for rows the exact path has written to
+        if (valid) {
+            if (word_stores && bad == 0 && (nm & 3) == 0) {
+                *reinterpret_cast<unsigned*>(orow) = codes_lo;
+                if (nm == 8) *reinterpret_cast<unsigned*>(orow + 4) = codes_hi;
+            } else {
+#pragma unroll
+                for (int g = 0; g < MG; ++g)
+                    if (g < nm && !((bad >> g) & 1u)) orow[g] = (uint8_t)((g < 4 ? codes_lo : codes_hi) >> (8 * (g & 3)));
             }
         }
     }

@@ -284,7 +284,7 @@ int32_t codebook_create_impl(pqhip_ctx* ctx, const float* quantizers, int64_t M,
 
     // 2-float sub-vectors: candidate tables (Pq handles only: the centroids of a k-means handle move)
     Vor2Tables vor2;
-    if (dsub == 2 && K <= 256 && only_slot < 0 && T != 0 && vor2_build(quantizers, M, K, vor2)) {
+    if (dsub <= 2 && K <= 256 && only_slot < 0 && T != 0 && vor2_build(quantizers, M, K, dsub, vor2)) {
         cb->vor2 = true;
         cb->vor2_max_region_words = vor2.max_region_words;
     }
@@ -384,12 +384,12 @@ int32_t pqhip_set_encode_variant(pqhip_codebook* cb, int32_t variant)
     return PQHIP_OK;
 }
 
-int32_t pqhip_vor2_tables_host(const float* quantizers, int64_t M, int64_t K, uint32_t* words_out, int64_t words_cap,
+int32_t pqhip_vor2_tables_host(const float* quantizers, int64_t M, int64_t K, int64_t dsub, uint32_t* words_out, int64_t words_cap,
                                uint32_t* region_off_out, int64_t* n_words)
 {
-    if (!quantizers || !n_words || M <= 0 || K <= 0) return PQHIP_EINVAL;
+    if (!quantizers || !n_words || M <= 0 || K <= 0 || dsub < 1 || dsub > 2) return PQHIP_EINVAL;
     Vor2Tables t;
-    if (!vor2_build(quantizers, M, K, t)) return PQHIP_EUNSUPPORTED;
+    if (!vor2_build(quantizers, M, K, dsub, t)) return PQHIP_EUNSUPPORTED;
     *n_words = (int64_t)t.words.size();
     if (words_out) {
         if (words_cap < (int64_t)t.words.size()) return PQHIP_EINVAL;

@@ -123,11 +123,11 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     // centroid): d=20 M=10 K=128 (the reference's test shape) 1.22e10 / 5.3e9, K=256 9.3e9 / 2.5e9, K=32 1.44e10 / 1.31e10;
     // d=64 M=32 K=128 3.3e9 / 1.75e9; d=300 M=150 K=256 3.4e8 / 1.7e8.  Up to 16 centroids the pair kernel below is faster
     // (d=128 M=64 K=16: 3.6e9 against 1.8e9 here).
-    if ((cb->variant == 11 || (cb->variant == 0 && cb->K > 16)) && cb->vor2 && code_bytes == 1 && cb->norms_ok && bad_flag == nullptr) {
+    if ((cb->variant == 11 || (cb->variant == 0 && (cb->K > 16 || cb->dsub == 1))) && cb->vor2 && code_bytes == 1 && cb->norms_ok && bad_flag == nullptr) {
         Vor2Launch l;
         l.x = d_x; l.n = n; l.x_rs = x_rs; l.out = (uint8_t*)d_codes; l.o_rs = o_rs;
         l.cb = cd.cb; l.cc = cd.cc; l.tab = cd.vor2_tab; l.off = cd.vor2_off;
-        l.M = (int)cb->M; l.K = (int)cb->K; l.k_pad = cb->k_pad; l.max_region_words = cb->vor2_max_region_words;
+        l.M = (int)cb->M; l.K = (int)cb->K; l.k_pad = cb->k_pad; l.dsub = (int)cb->dsub; l.max_region_words = cb->vor2_max_region_words;
         l.n_cus = cb->ctx->devs[slot]->n_cus;
         if (launch_vor2(l, st)) {
             HIPCHK(hipGetLastError());

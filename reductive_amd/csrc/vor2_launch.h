@@ -8,7 +8,7 @@ namespace pqhip {
 struct Vor2Launch {
     const float* x; int64_t n, x_rs; uint8_t* out; int64_t o_rs;
     const float* cb; const float* cc; const uint32_t* tab; const uint32_t* off;
-    int M, K, k_pad;
+    int M, K, k_pad, dsub;
     uint32_t max_region_words;
     int n_cus;
 };

@@ -18,7 +18,7 @@ bool launch_vor2(const Vor2Launch& l, hipStream_t st)
     const size_t lds = per_m * (size_t)mg;
     Vor2Args a;
     a.x = l.x; a.n = l.n; a.x_rs = l.x_rs; a.out = l.out; a.o_rs = l.o_rs; a.cb = l.cb; a.cc = l.cc; a.tab = l.tab; a.off = l.off;
-    a.M = l.M; a.K = l.K; a.k_pad = l.k_pad; a.mg = mg;
+    a.M = l.M; a.K = l.K; a.k_pad = l.k_pad; a.dsub = l.dsub; a.mg = mg;
     // rows per thread: the tables are staged once per workgroup, so as many as leave about four rounds of workgroups per group
     // (rows per thread 4 / 8 / 16 / 32 / 64 at the shape above: 0.835 / 0.786 / 0.775 / 0.786 / 0.790 ms)
     const int64_t slots = (int64_t)l.n_cus * std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)std::max<size_t>(lds, 1))) * 4;

@@ -30,15 +30,16 @@
 
 namespace pqhip {
 
-// Per subquantizer, 32-bit words: [0] lo0 [1] inv0 [2] lo1 [3] inv1 [4] G (as float) [5..8] the same for the coarse grid
-// [9] CG (float) [10] index of the fine cell table's first 16-bit entry [11] of the coarse one's [15] of the sub-cell table's
-// (all counted in 16-bit units from the region's first word) [12] BYTE offset of the lists [13] G (int) [14] CG (int); then the
+// Per subquantizer, 32-bit words: [0] lo0 [1] inv0 [2] lo1 [3] inv1 [4] G0 (cells along axis 0, as float) [16] G1 (float)
+// [5..8] the same for the coarse grid [9] CG0 (float) [17] CG1 (float) [10] index of the fine cell table's first 16-bit entry
+// [11] of the coarse one's [15] of the sub-cell table's (all counted in 16-bit units from the region's first word) [12] BYTE
+// offset of the lists [13] G1 (int: cell = i0 G1 + i1) [14] CG1 (int) [18] [19] unused; then the
 // cell tables and the lists.  A cell entry is u16: list offset in words << 4 | words - 1 (lists: u8 centroid indices, ascending;
 // every list starts on a word and is padded to whole words with its last index; at most 16 words).  A FINE cell entry whose
 // length field is 15 is subdivided: bits 15..4 number a group of four entries in the sub-cell table, one per half cell
 // (2 [t0 - floor(t0) >= 0.5] + [t1 - floor(t1) >= 0.5]), each a plain entry (up to 16 words; plain FINE entries: 15).  The list of a coarse cell
 // covers the part of the cell outside the fine grid only.  Offsets are relative to the region's first word.
-constexpr int kVor2HeaderWords = 16;
+constexpr int kVor2HeaderWords = 20;
 
 struct Vor2Tables {
     std::vector<uint32_t> words;        // all regions, back to back
@@ -47,6 +48,6 @@ struct Vor2Tables {
 };
 
 // false: the codebook is not eligible (non-finite or extreme centroids, K > 256, a list region too large)
-bool vor2_build(const float* quantizers, int64_t M, int64_t K, Vor2Tables& out);
+bool vor2_build(const float* quantizers, int64_t M, int64_t K, int64_t dsub, Vor2Tables& out);   // dsub 1 or 2
 
 }  // namespace pqhip

@@ -73,23 +73,23 @@ def launch_log(reset=False):
 
 
 def vor2_tables(quantizers):
-    """The candidate tables of the 2-float sub-vector encode kernel for `quantizers` [M][K][2], built on the host exactly as
+    """The candidate tables of the 2-float sub-vector encode kernel for `quantizers` [M][K][2] (or [M][K][1]), built on the host exactly as
     at codebook creation (include/pqhip.h: pqhip_vor2_tables_host; layout: csrc/vor2_prep.h).  Returns (words uint32[],
     region_off uint32[M + 1]) or None when the codebook is not eligible.  Needs no GPU."""
     q = np.ascontiguousarray(quantizers, dtype=np.float32)
-    if q.ndim != 3 or q.shape[2] != 2:
-        raise ReductiveError("vor2_tables: quantizers must be [M][K][2]")
+    if q.ndim != 3 or q.shape[2] not in (1, 2):
+        raise ReductiveError("vor2_tables: quantizers must be [M][K][1] or [M][K][2]")
     L = _lib.lib()
-    M, K = q.shape[0], q.shape[1]
+    M, K, dsub = q.shape
     n = ctypes.c_int64(0)
     off = np.zeros(M + 1, dtype=np.uint32)
-    rc = L.pqhip_vor2_tables_host(q.ctypes.data, M, K, None, 0, None, ctypes.byref(n))
+    rc = L.pqhip_vor2_tables_host(q.ctypes.data, M, K, dsub, None, 0, None, ctypes.byref(n))
     if rc == _lib.EUNSUPPORTED:
         return None
     if rc != _lib.OK:
         raise _lib.PqHipError(rc, "pqhip_vor2_tables_host")
     words = np.zeros(n.value, dtype=np.uint32)
-    rc = L.pqhip_vor2_tables_host(q.ctypes.data, M, K, words.ctypes.data, words.size, off.ctypes.data, ctypes.byref(n))
+    rc = L.pqhip_vor2_tables_host(q.ctypes.data, M, K, dsub, words.ctypes.data, words.size, off.ctypes.data, ctypes.byref(n))
     if rc != _lib.OK:
         raise _lib.PqHipError(rc, "pqhip_vor2_tables_host")
     return words, off

@@ -166,4 +166,4 @@ def test_random_kmeans_iterations_match_oracle(ra, seed):
 
 
 def test_zz_the_seeds_reach_every_kernel_family(ra):
-    assert {"k_encode_small16", "k_encode_vor2", "k_encode_mfma_lds3", "k_encode_mfma"} <= SEEN, SEEN
+    assert {"k_encode_small16", "k_encode_vor2", "k_encode_mfma_lds3"} <= SEEN, SEEN

@@ -74,6 +74,40 @@ def test_ties_duplicates_and_uniform_data(ra):
     assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("M,K,n", [(128, 256, 20_001), (300, 256, 3_000), (16, 16, 70_000), (7, 1, 100), (64, 100, 9_999), (1, 256, 1)])
+def test_one_float_sub_vectors(ra, M, K, n):
+    """A codebook per dimension (dsub = 1, scalar quantization with learned levels): the candidate-list kernel with the second
+    coordinate 0; codes equal the oracle's, special values and out-of-grid rows included."""
+    import torch
+    rng = np.random.default_rng(9650 + M + K)
+    q = rng.standard_normal((M, K, 1)).astype(np.float32)
+    x = synth.normalish(9651 + M + K + n, (n, M))
+    if n > 40:
+        x[3, 0] = np.nan
+        x[4, M - 1] = np.inf
+        x[5] *= np.float32(1e19)
+        x[6] *= np.float32(20.0)
+        x[7] *= np.float32(500.0)
+        x[8, 0] = q[0, K - 1, 0]
+        x[n - 1] = -np.inf
+        x[20:30] = 0.0
+    pq = ra.Pq(None, q)
+    with np.errstate(all="ignore"):
+        want = orc.quantize_batch(q, x, n_threads=8)
+    xd = torch.from_numpy(x).cuda()
+    got = pq.quantize_batch_device(xd).cpu().numpy()
+    assert pq.last_encode_kernel() == "k_encode_vor2"
+    assert got.tobytes() == want.tobytes()
+    wide = torch.zeros((n, M + 3), device="cuda")
+    wide[:, 1:M + 1] = xd
+    out = torch.full((n, M + 2), 254, device="cuda", dtype=torch.uint8)
+    pq.quantize_batch_device(wide[:, 1:M + 1], out=out[:, :M])
+    assert out[:, :M].cpu().numpy().tobytes() == want.tobytes() and int((out[:, M:] != 254).sum()) == 0
+    other = ra.Pq(None, q)
+    other.set_encode_variant(4)
+    assert other.quantize_batch_device(xd).cpu().numpy().tobytes() == want.tobytes()
+
+
 def test_opq_rotation_then_candidate_lists(ra):
     """`Pq` with a projection and 2-float sub-vectors: the rotated rows (scratch chunks of the two-kernel OPQ path) go through
     the candidate-list kernel; codes equal the oracle's (pq.rs:276-282)."""

@@ -21,7 +21,7 @@ def ra():
 
 def walk(words, off, q, x):
     """The kernel's walk, vectorised over rows: returns codes [n][M] with -1 where the row takes the exact path."""
-    M, K, _ = q.shape
+    M, K, dsub = q.shape
     n = x.shape[0]
     out = np.full((n, M), -1, dtype=np.int64)
     lists_seen = []
@@ -29,15 +29,15 @@ def walk(words, off, q, x):
     for m in range(M):
         r = words[off[m]:off[m + 1]]
         hf = r.view(np.float32)
-        x0 = x[:, 2 * m].astype(f32)
-        x1 = x[:, 2 * m + 1].astype(f32)
+        x0 = x[:, dsub * m].astype(f32)
+        x1 = x[:, 2 * m + 1].astype(f32) if dsub == 2 else np.zeros(n, dtype=f32)   # 1 float: the second coordinate is 0
         with np.errstate(all="ignore"):
             t0 = (x0 - hf[0]) * hf[1]
             t1 = (x1 - hf[2]) * hf[3]
             u0 = (x0 - hf[5]) * hf[6]
             u1 = (x1 - hf[7]) * hf[8]
-            in_f = (t0 >= 0) & (t0 < hf[4]) & (t1 >= 0) & (t1 < hf[4])
-            in_c = (u0 >= 0) & (u0 < hf[9]) & (u1 >= 0) & (u1 < hf[9])
+            in_f = (t0 >= 0) & (t0 < hf[4]) & (t1 >= 0) & (t1 < hf[16])
+            in_c = (u0 >= 0) & (u0 < hf[9]) & (u1 >= 0) & (u1 < hf[17])
         G, CG = int(r[13]), int(r[14])
         s0 = np.where(in_f, t0, np.where(in_c, u0, 0)).astype(np.int64)
         s1 = np.where(in_f, t1, np.where(in_c, u1, 0)).astype(np.int64)
@@ -58,6 +58,8 @@ def walk(words, off, q, x):
         best = np.full(n, np.inf, dtype=f32)
         bj = np.full(n, -1, dtype=np.int64)
         c = q[m].astype(f32)
+        if dsub == 1:
+            c = np.concatenate([c, np.zeros_like(c)], axis=1)
         cc = (c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1]).astype(f32)
         for i in range(int(nwords.max()) if n else 0):
             act = i < nwords
@@ -206,3 +208,27 @@ def test_ineligible_codebooks(ra):
         b[1, 3, 0] = bad
         assert ra.vor2_tables(b) is None
     assert ra.vor2_tables(synth.normalish(9501, (1, 257, 2))) is None
+
+
+@pytest.mark.parametrize("K", [1, 2, 16, 100, 256])
+def test_one_float_sub_vectors(ra, K):
+    """A codebook per dimension (dsub = 1): the same tables with every centroid on the x axis; the walk's 2-float formulas with a
+    zero second coordinate are CANON-F32's 1-float distances bit for bit, so the result must again be the oracle's code --
+    gaussian rows, rows over both grids and beyond, every cell edge with its float neighbours, midpoints of neighbouring
+    centroids, duplicated centroids."""
+    M = 6
+    rng = np.random.default_rng(9800 + K)
+    q = rng.standard_normal((M, K, 1)).astype(np.float32)
+    if K > 4:
+        q[1, K - 1] = q[1, 0]
+    x = rng.standard_normal((60_000, M)).astype(np.float32)
+    x[20_000:40_000] = (rng.random((20_000, M)).astype(np.float32) - np.float32(0.5)) * np.float32(80.0)
+    words, off = ra.vor2_tables(q)
+    for m in range(M):
+        hf = words[off[m]:off[m + 1]].view(np.float32)
+        edges = (np.float64(hf[0]) + np.arange(int(hf[4]) + 1) / np.float64(hf[1])).astype(np.float32)
+        vals = np.concatenate([edges, np.nextafter(edges, np.float32(-np.inf)), np.nextafter(edges, np.float32(np.inf))])
+        srt = np.sort(q[m, :, 0])
+        vals = np.concatenate([vals, ((srt[:-1].astype(np.float64) + srt[1:]) / 2).astype(np.float32), q[m, :, 0]])
+        x[40_000:40_000 + vals.size, m] = vals[:20_000]
+    check(ra, q, x)
