@@ -1,7 +1,7 @@
 // kernels_vor2.hip.h -- PQ encode for 2-float (and 1-float) sub-vectors (K <= 256): only the centroids that can win in the point's grid cell
 // are evaluated (round 4; the tables and the argument why the first minimum is always among them: vor2_prep.h).
 //
-// One LANE owns one row and walks the subquantizers of the workgroup's group (blockIdx.y); the group's tables -- grid
+// One LANE owns one row and walks the subquantizers of the workgroup's group; the group's tables -- grid
 // parameters, 16-bit cell entries (list offset, length in words), the lists of centroid indices -- its centroids and their norms live in LDS.
 // Per (row, m): the cell from two subtract-multiply pairs (exactly the operations the tables were built for; the grid parameters
 // come through the scalar path), one LDS word for the cell, then the list four indices (one word) at a time: four independent
@@ -29,28 +29,43 @@ struct Vor2Args {
     const uint32_t* off;  // [M + 1] word offsets into tab
     int M, K, k_pad;
     int dsub;             // 1 or 2 floats per sub-vector (1: the second coordinate is 0 everywhere)
-    int mg;               // subquantizers per workgroup (blockIdx.y selects the group)
+    int mg;               // subquantizers per workgroup
     int rows_per_thread;
+    int n_groups;         // groups of mg subquantizers
+    int64_t n_row_blocks; // blocks of (threads per workgroup) * rows_per_thread rows
 };
 
 // read-only for the whole launch: loads through the constant address space stay on the scalar path (see kernels_smallk.hip.h)
 typedef const uint32_t __attribute__((address_space(4)))* vor2_cptr;
 
-template <int MG>   // subquantizers per workgroup, at most (a.mg <= MG)
-__global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
+// MG: subquantizers per workgroup, at most (a.mg <= MG).  NT: threads per workgroup -- 256, or 512 when the row is cut into eight groups or
+// more: a group then reads a short piece of a long row, the wait for those lines is what the waves of a CU have to cover, and
+// eight waves share one copy of the tables (d = 300, M = 150, K = 256: 14.3 -> 11.1 ms per 10 M rows; 128 one-float
+// sub-vectors: 8.2 -> 4.9 ms; with up to four groups 256 threads are 5-10 % faster)
+template <int MG, int NT>
+__global__ __launch_bounds__(NT) void k_encode_vor2(Vor2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t vor2_s[];
     const vor2_cptr off_c = (vor2_cptr)a.off;
     const vor2_cptr tab_c = (vor2_cptr)a.tab;
-    const int m0 = blockIdx.y * a.mg;
+    // workgroup -> (row block, group), XCD-aware: workgroups are handed to the eight XCDs round robin, so the groups of one row
+    // block are given ids of the same residue -- they run on one XCD at about the same time and its L2 fetches the rows' lines
+    // once for all of them (a group reads only its 8 to 64 bytes of every row)
+    const int64_t wg = blockIdx.x;
+    const int64_t wl = wg >> 3;
+    const int64_t rbl = wl / a.n_groups;
+    const int grp = (int)(wl - rbl * a.n_groups);
+    const int64_t row_block = rbl * 8 + (wg & 7);
+    if (row_block >= a.n_row_blocks) return;
+    const int m0 = grp * a.mg;
     const int nm = (a.M - m0 < a.mg) ? a.M - m0 : a.mg;
     const uint32_t w0 = off_c[m0];
     const uint32_t nw_raw = off_c[m0 + nm] - w0;
     const uint32_t nw = (nw_raw + 3u) & ~3u;                       // table words of the group (the records below start on 16 bytes)
     // LDS: [tables of the group][records: nm x K x {c0, c1, ||c||^2, -}]
     f32x4* const rec_s = reinterpret_cast<f32x4*>(vor2_s + nw);
-    for (uint32_t i = threadIdx.x; i < nw_raw; i += 256) vor2_s[i] = a.tab[w0 + i];
-    for (int i = threadIdx.x; i < nm * a.K; i += 256) {
+    for (uint32_t i = threadIdx.x; i < nw_raw; i += NT) vor2_s[i] = a.tab[w0 + i];
+    for (int i = threadIdx.x; i < nm * a.K; i += NT) {
         const int g = i / a.K, j = i - g * a.K;
         const float* c = a.cb + ((int64_t)(m0 + g) * a.K + j) * a.dsub;
         rec_s[i] = (f32x4){c[0], a.dsub == 2 ? c[1] : 0.f, a.cc[(int64_t)(m0 + g) * a.k_pad + j], 0.f};
@@ -59,14 +74,14 @@ __global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
 
     const int lane = threadIdx.x & 63;
     const bool word_stores = (a.o_rs % 4 == 0) && (m0 % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.out) & 3) == 0);
-    const int64_t block_row0 = (int64_t)blockIdx.x * 256 * a.rows_per_thread;
+    const int64_t block_row0 = row_block * NT * a.rows_per_thread;
     // the row's floats of the group: requested one row ahead
     float xn[2 * MG];
     const int nfl = a.dsub * nm;                                   // floats of the group per row
     // 16-byte loads when the group's floats start on 16 bytes in every row (row stride, base and first column)
     const bool vec4 = (a.x_rs % 4 == 0) && ((a.dsub * m0) % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
     auto fetch = [&](int it) {
-        int64_t row = block_row0 + (int64_t)it * 256 + threadIdx.x;
+        int64_t row = block_row0 + (int64_t)it * NT + threadIdx.x;
         if (row >= a.n) row = a.n - 1;
         const float* xr = a.x + row * a.x_rs + a.dsub * m0;
         if (vec4) {                                                // (wave-uniform; whole pieces: the row has them, x_rs >= d)
@@ -91,7 +106,7 @@ __global__ __launch_bounds__(256) void k_encode_vor2(Vor2Args a)
     };
     fetch(0);
     for (int it = 0; it < a.rows_per_thread; ++it) {
-        const int64_t wave_row0 = block_row0 + (int64_t)it * 256 + (threadIdx.x & ~63);
+        const int64_t wave_row0 = block_row0 + (int64_t)it * NT + (threadIdx.x & ~63);
         if (wave_row0 >= a.n) break;                               // wave-uniform
         const int64_t row = wave_row0 + lane;
         const bool valid = row < a.n;

@@ -120,9 +120,9 @@ int32_t encode_plain_dev(pqhip_codebook* cb, int slot, const float* d_x, int64_t
     // 2-float sub-vectors, K <= 256: only the centroids that can win in the point's grid cell are evaluated (kernels_vor2.hip.h;
     // the tables exist for Pq handles whose centroids are finite and within range).  Variant 11 forces it.
     // Auto above 16 centroids (tools: bench.py --d .. --variant 0 / 2 / 4, vectors/s against the best kernel that evaluates every
-    // centroid): d=20 M=10 K=128 (the reference's test shape) 1.22e10 / 5.3e9, K=256 9.3e9 / 2.5e9, K=32 1.44e10 / 1.31e10;
-    // d=64 M=32 K=128 3.3e9 / 1.75e9; d=300 M=150 K=256 3.4e8 / 1.7e8.  Up to 16 centroids the pair kernel below is faster
-    // (d=128 M=64 K=16: 3.6e9 against 1.8e9 here).
+    // centroid): d=20 M=10 K=128 (the reference's test shape) 1.7e10 / 5.3e9, K=256 1.5e10 / 2.5e9, K=32 1.44e10 / 1.31e10;
+    // d=64 M=32 K=128 6.3e9 / 1.75e9; d=300 M=150 K=256 9.3e8 / 1.7e8; one-float sub-vectors d=128 M=128 K=256 2.0e9 / 2.0e8.
+    // Up to 16 centroids the pair kernel below is faster (d=128 M=64 K=16: 3.6e9 against 1.8e9 here).
     if ((cb->variant == 11 || (cb->variant == 0 && (cb->K > 16 || cb->dsub == 1))) && cb->vor2 && code_bytes == 1 && cb->norms_ok && bad_flag == nullptr) {
         Vor2Launch l;
         l.x = d_x; l.n = n; l.x_rs = x_rs; l.out = (uint8_t*)d_codes; l.o_rs = o_rs;
