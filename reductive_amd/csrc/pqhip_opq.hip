@@ -4,6 +4,7 @@
 #include "pqhip_internal.h"
 
 #include "kernels_gather.hip.h"
+#include "kernels_gather_cg.hip.h"
 #include "opq_fused2_launch.h"
 
 using namespace pqhip;
@@ -96,6 +97,50 @@ static int32_t gather_compact(pqhip_codebook* cb, int slot, const void* d_codes,
     CodebookDev& cd = cb->dev[slot];
     const int d = (int)cb->d;
     const bool sel = sel_rows != nullptr || sel_scales != nullptr;            // the SEL form of the kernel
+    // short sub-vectors (1 or 2 floats), K <= 256, 1-byte codes: centroids from LDS, a group of subquantizers per workgroup
+    // (kernels_gather_cg.hip.h; four-float sub-vectors measured no faster there and stay below)
+    if (code_bytes == 1 && cb->K <= 256 && (cb->dsub == 1 || cb->dsub == 2) && d % 4 == 0 && o_rs % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && n < (1ll << 40)) {
+        const int dsub = (int)cb->dsub, cpc = 4 / dsub;
+        const size_t per_m = (size_t)cb->K * dsub * sizeof(float);
+        // subquantizers per group: 64 KB of centroids (two workgroups per CU), whole 128-byte pieces of the output row where possible,
+        // at most 64 chunks per row and group
+        int64_t mg = (int64_t)((64 * 1024) / per_m);
+        const int unit = 32 / dsub;
+        mg = mg >= unit ? mg / unit * unit : mg / cpc * cpc;
+        mg = std::min<int64_t>(std::min<int64_t>(mg, 256 / dsub), cb->M);
+        const int n_groups = (int)((cb->M + mg - 1) / mg);
+        const size_t lds = (size_t)mg * per_m;
+        const int cpr = (int)(mg / cpc);
+        RecCgArgs a;
+        a.codes = (const uint8_t*)d_codes; a.n = n; a.c_rs = c_rs; a.out = d_out; a.o_rs = o_rs; a.cb = cd.cb;
+        a.M = (int)cb->M; a.K = (int)cb->K; a.mg = (int)mg; a.n_groups = n_groups; a.err = err;
+        a.sel_rows = sel_rows; a.n_codes = n_codes; a.sel_scales = sel_scales; a.s_rs = s_rs;
+        // rows per workgroup: the staged centroids are paid once per workgroup -- about eight times their bytes in output, and no
+        // fewer workgroups than fill the device twice
+        int64_t rpw = round_up((int64_t)(8 * lds) / (cpr * 16), 64);
+        rpw = std::max<int64_t>(256, std::min<int64_t>(4096, rpw));
+        const int64_t fill = round_up(std::max<int64_t>(64, n * n_groups / ((int64_t)cus_of(cb, slot) * 4)), 64);
+        rpw = std::min<int64_t>(rpw, fill);
+        a.rows_per_wg = (int)rpw;
+        a.sb_rows = std::max(1, 32768 / cpr);
+        a.n_row_blocks = (n + rpw - 1) / rpw;
+        const int64_t n_wg = ((a.n_row_blocks + 7) / 8) * 8 * n_groups;
+        if (n_wg <= 0x7fffffffll) {
+#define LAUNCH_CG(DS, SELT)                                                                                              \
+    do {                                                                                                                 \
+        if (lds > 48 * 1024)                                                                                             \
+            HIPCHK(hipFuncSetAttribute((const void*)k_reconstruct_cg<DS, SELT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+        hipLaunchKernelGGL((k_reconstruct_cg<DS, SELT>), dim3((unsigned)n_wg), dim3(512), lds, st, a);                   \
+    } while (0)
+            if (dsub == 1) { if (sel) LAUNCH_CG(1, true); else LAUNCH_CG(1, false); }
+            else { if (sel) LAUNCH_CG(2, true); else LAUNCH_CG(2, false); }
+#undef LAUNCH_CG
+            HIPCHK(hipGetLastError());
+            note_kernel(sel_rows ? "k_reconstruct_cg<lookup>" : sel ? "k_reconstruct_cg<scaled>" : "k_reconstruct_cg");
+            return PQHIP_OK;
+        }
+    }
     // 16-byte output chunks whenever a row is a whole number of them (the stores are dword-aligned
     // wide stores, so neither the row stride nor the base address matters); a chunk is filled with
     // one, two or four codebook accesses depending on how sub-vectors line up with it
