@@ -34,6 +34,7 @@ SHAPES = [  # d, M, K, n
     (4, 2, 3, 1),
     (512, 256, 16, 3_000),      # many subquantizers, small codebooks: the 64-chunk cap per group
     (1024, 1024, 256, 600),
+    (300, 150, 256, 1), (300, 150, 256, 2), (300, 150, 256, 511), (300, 150, 256, 513), (300, 300, 100, 65),
 ]
 
 

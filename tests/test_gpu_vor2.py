@@ -23,7 +23,8 @@ def ra():
 
 
 @pytest.mark.parametrize("M,K,n", [(10, 128, 200_003), (1, 1, 100), (3, 2, 4097), (7, 17, 10_000), (37, 47, 5_001), (5, 48, 70_000),
-                                    (150, 256, 3_000), (64, 255, 9_999), (10, 128, 1), (2, 200, 64)])
+                                    (150, 256, 3_000), (64, 255, 9_999), (10, 128, 1), (2, 200, 64),
+                                    (150, 256, 1), (150, 64, 513), (100, 200, 511), (66, 256, 65)])   # eight groups or more, a few rows
 def test_codes_equal_oracle(ra, M, K, n):
     import torch
     rng = np.random.default_rng(9600 + M + K)
@@ -74,7 +75,8 @@ def test_ties_duplicates_and_uniform_data(ra):
     assert got.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("M,K,n", [(128, 256, 20_001), (300, 256, 3_000), (16, 16, 70_000), (7, 1, 100), (64, 100, 9_999), (1, 256, 1)])
+@pytest.mark.parametrize("M,K,n", [(128, 256, 20_001), (300, 256, 3_000), (16, 16, 70_000), (7, 1, 100), (64, 100, 9_999), (1, 256, 1),
+                                    (128, 256, 1), (128, 256, 515), (300, 100, 63)])
 def test_one_float_sub_vectors(ra, M, K, n):
     """A codebook per dimension (dsub = 1, scalar quantization with learned levels): the candidate-list kernel with the second
     coordinate 0; codes equal the oracle's, special values and out-of-grid rows included."""
