@@ -1,12 +1,13 @@
 #!/bin/bash
 # Runs on the GPU box: SQ counters of one kernel under tools/sk_time.py (or any command after the tag), a few counters per pass.
-# usage: tools/sq_counters.sh <tag> <python script and args ...>
+# usage: [KFILTER=k_reconstruct] tools/sq_counters.sh <tag> <python script and args ...>   (KFILTER: substring of the kernel names kept, default k_encode)
 set -u
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp PYTHONPATH=$R
+KF=${KFILTER:-k_encode}
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/"$@" > $OUT/stats.out 2> $OUT/stats.err || echo "stats pass failed"
 i=0
@@ -22,10 +23,10 @@ tot = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$OUT/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        if "k_encode" not in k: continue
+        if "$KF" not in k: continue
         key = (k.split("(")[0][:60], r["Counter_Name"])
         tot[key][0] += float(r["Counter_Value"]); tot[key][1] += 1
 for (k, c), (v, n) in sorted(tot.items()):
     print("%-60s %-32s %14.0f per launch (%d launches)" % (k, c, v / n, n))
 PY
-grep -h "k_encode" $OUT/stats/*/*kernel_stats.csv 2>/dev/null | head -5
+grep -h "$KF" $OUT/stats/*/*kernel_stats.csv 2>/dev/null | head -5
