@@ -322,7 +322,18 @@ class Bench:
                     "kernel": kernel,
                     "avg_launch_ms": kernel_ms, "min_launch_ms": kmin, "max_launch_ms": kmax,
                     "algorithmic_flop_per_vector": flop, "algorithmic_bytes_per_vector": bytes_vec,
-                    "hbm_gbs": bytes_vec * rows / sec / 1e9, "hbm_frac": bytes_vec * rows / sec / 1e9 / PEAK_HBM_GBS}
+                    "hbm_gbs": bytes_vec * rows / sec / 1e9, "hbm_frac": bytes_vec * rows / sec / 1e9 / PEAK_HBM_GBS,
+                    "mfma_frac": ach / PEAK_F32_MFMA_TFLOPS}
+            # The candidate-list kernel evaluates a handful of the K distances per sub-vector and issues no matrix instruction: the
+            # flop of the full distance matrix is an equivalent, not work it does.  Its governing roofline is HBM (rows in, codes
+            # out); the equivalent stays in the record under its own name.
+            if workload == "encode" and isinstance(kernel, str) and "k_encode_vor2" in kernel:
+                roof.update({"bound": "hbm", "achieved": roof["hbm_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": roof["hbm_frac"],
+                             "full_distance_matrix_tflops_equivalent": ach})
+            # small codebooks (K = 16: 32 flop per byte): the HBM roofline is the nearer one -- it governs, the matrix fraction stays beside it
+            elif workload == "encode" and roof["hbm_frac"] > roof["frac"]:
+                roof.update({"bound": "hbm", "achieved": roof["hbm_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": roof["hbm_frac"],
+                             "mfma_tflops": ach})
         if workload != "kmeans":
             roof["launch_ms"] = list(getattr(self, "last_launch_ms", []))[:32]     # every timed step, in order
         if traffic_rec:
@@ -469,7 +480,10 @@ def main():
             # the reference's OWN shapes (not BASELINE configs): its criterion bench (benches/pq.rs:9-10) and its statistical
             # test (pq.rs:431-440), 10 M rows each, same record form
             refs = {}
-            for key, (sd, sm, sk) in (("benches_pq_rs_d128_M16_K16", (128, 16, 16)), ("pq_rs_test_d20_M10_K128", (20, 10, 128))):
+            # (third: M = d / 2 two-float sub-vectors at the headline dimension -- the shape finalfusion's own quantizer front end
+            # is remembered to default to; nothing in /root/reference pins it)
+            for key, (sd, sm, sk) in (("benches_pq_rs_d128_M16_K16", (128, 16, 16)), ("pq_rs_test_d20_M10_K128", (20, 10, 128)),
+                                      ("half_dim_d300_M150_K256", (300, 150, 256))):
                 try:
                     r = b.run("encode", 10_000_000, sd, sm, sk, max(1, min(args.steps, args.sub_steps)), min(2, max(1, args.warmup)))
                     refs[key] = record("encode", r, 1)

@@ -7,7 +7,7 @@ for s in "300 150 256" "300 100 256" "300 75 256" "300 60 256" "300 50 256" "128
     env $envv python bench.py --d $1 --m $2 --k $3 --variant $var --steps 8 --warmup 2 --no-cpu-baseline --no-sub-configs 2>/dev/null | python -c "
 import json,sys
 try:
-    r=json.loads(sys.stdin.read()); ro=r['roofline']; print('d=$1 M=$2 K=$3 $name', r['encode_kernel'], '%.3e vec/s' % r['value'], 'mfma_frac %.3f' % ro['frac'], 'hbm_frac %.3f' % ro['hbm_frac'])
+    r=json.loads(sys.stdin.read()); ro=r['roofline']; print('d=$1 M=$2 K=$3 $name', r['encode_kernel'], '%.3e vec/s' % r['value'], 'mfma_frac %.3f' % ro.get('mfma_frac', ro['frac']), 'hbm_frac %.3f' % ro['hbm_frac'])
 except Exception as e: print('d=$1 M=$2 K=$3 $name failed')"
   done
 done

@@ -7,7 +7,7 @@ while read d m k rows; do
   python3 - "$d" "$m" "$k" "$rows" <<PY
 import json, sys
 r = json.loads('''$out''')
-print("d=%s M=%s K=%s rows=%s  %.3e vec/s  %.2f ms  mfma_frac=%.3f  hbm=%.0f GB/s  %s" % (*sys.argv[1:5], r["value"], r["ms_per_step"], r["roofline"]["frac"], r["roofline"]["hbm_gbs"], r["encode_kernel"]))
+print("d=%s M=%s K=%s rows=%s  %.3e vec/s  %.2f ms  mfma_frac=%.3f  hbm=%.0f GB/s  %s" % (*sys.argv[1:5], r["value"], r["ms_per_step"], r["roofline"].get("mfma_frac", r["roofline"]["frac"]), r["roofline"]["hbm_gbs"], r["encode_kernel"]))
 PY
 done <<LIST
 300 15 256 10000000
