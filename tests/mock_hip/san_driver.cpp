@@ -45,7 +45,8 @@ static int devices_mode()
     // (the last two: the small-codebook kernels of round 4 -- 16x16x4 with the codebook image in LDS, and the candidate-list
     // kernel for 2-float sub-vectors, whose tables are built on the host and replicated on every device)
     for (const Shape sh : {Shape{15, 256, 20, 400003, false}, Shape{48, 256, 16, 90001, false}, Shape{15, 256, 20, 70001, true},
-                           Shape{16, 16, 8, 50001, false}, Shape{10, 128, 2, 60001, false}}) {
+                           Shape{16, 16, 8, 50001, false}, Shape{10, 128, 2, 60001, false},
+                           Shape{150, 256, 2, 30001, false}, Shape{128, 64, 1, 20001, false}}) {   // many groups of subquantizers (candidate lists, grouped reconstruct)
         const int64_t M = sh.M, K = sh.K, dsub = sh.dsub, d = M * dsub, n = sh.n;
         std::vector<float> q((size_t)(M * K * dsub)), P;
         for (size_t i = 0; i < q.size(); ++i) q[i] = (float)((i * 2654435761ull >> 8) & 0xffff) / 65536.0f;   // distinct centroids
