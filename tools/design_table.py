@@ -17,6 +17,8 @@ names = [("encode@10000000@d300_m15_k256", "PQ encode 10 M × 300, M = 15 (confi
          ("adc_scan@100000000@d300_m15_k256_q8", "ADC scan 100 M rows, 8 queries", "hbm", 47),
          ("encode@10000000@d128_m16_k16", "PQ encode d = 128, M = 16, K = 16 (benches/pq.rs shape)", "hbm", 528),
          ("encode@10000000@d20_m10_k128", "PQ encode d = 20, M = 10, K = 128 (pq.rs:431-440 test shape; candidate lists)", "hbm", 90),
+         ("encode@10000000@d300_m150_k256", "PQ encode d = 300, M = 150, K = 256 (two-float sub-vectors; candidate lists)", "hbm", 1350),
+         ("reconstruct@10000000@d300_m150_k256", "PQ reconstruct 10 M codes, d = 300, M = 150 (grouped LDS gather)", "hbm", 1350),
          ("kmeans@10000000@d300_m15_k256", "k-means iteration, 15 subquantizers, 10 M × 300", "mfma", 2 * 256 * 300),
          ("opq_train@10000000@d300_m15_k256", "OPQ training step, exact cross product", "mfma", 2 * 300 * 300 * 2 + 2 * 2 * 256 * 300),
          ("opq_train@10000000@d300_m15_k256_fastcross", "OPQ training step, float-tolerance cross product", "mfma", 2 * 300 * 300 * 2 + 2 * 2 * 256 * 300)]

@@ -15,7 +15,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-WL=${*:-"encode opq_encode reconstruct reconstruct100 encode_d768 lookup lookup100 adc_scan adc_scan8 opq_reconstruct kmeans opq_train opq_train_fast smallk testshape"}
+WL=${*:-"encode opq_encode reconstruct reconstruct100 encode_d768 lookup lookup100 adc_scan adc_scan8 opq_reconstruct kmeans opq_train opq_train_fast smallk testshape halfdim halfdim_rec"}
 for W in $WL; do
   case $W in
     reconstruct100) ARGS="--workload reconstruct --rows 100000000";;
@@ -24,6 +24,8 @@ for W in $WL; do
     opq_train_fast) ARGS="--workload opq_train --fast-cross";;
     smallk) ARGS="--workload encode --d 128 --m 16 --k 16";;
     testshape) ARGS="--workload encode --d 20 --m 10 --k 128";;
+    halfdim) ARGS="--workload encode --d 300 --m 150 --k 256";;
+    halfdim_rec) ARGS="--workload reconstruct --d 300 --m 150 --k 256 --rows 10000000";;
     *) ARGS="--workload $W";;
   esac
   CMD="$R/bench.py $ARGS --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-sub-configs"

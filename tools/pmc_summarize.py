@@ -95,7 +95,7 @@ for w in wls:
     c = b["config"]
     fetch_b = sum(f) / len(f) * 1024 * 2
     write_b = sum(wr) / len(wr) * 1024
-    wl_name = {"reconstruct100": "reconstruct", "adc_scan8": "adc_scan", "smallk": "encode", "testshape": "encode", "lookup100": "lookup",
+    wl_name = {"reconstruct100": "reconstruct", "adc_scan8": "adc_scan", "smallk": "encode", "testshape": "encode", "halfdim": "encode", "halfdim_rec": "reconstruct", "lookup100": "lookup",
                "opq_train_fast": "opq_train"}.get(w, w)
     key = "%s@%d@d%d_m%d_k%d" % (wl_name, c["rows_per_gpu"], c["d"], c["M"], c["K"])
     if b.get("queries_per_scan", 1) > 1:
