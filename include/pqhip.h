@@ -300,7 +300,11 @@ int32_t pqhip_set_rotation_variant(int32_t variant);
  *                          within 1e-5 relative of the exact rule-2 result, no per-block partial matrices (default 1)
  *   "cross_product_group_bytes"  workspace of partial matrices per launch group (0 = 4 GiB)
  *   "lookup_two_pass"      row lookups (pqhip_reconstruct_rows*): 0 = one kernel, 1 = select the code rows into a compact
- *                          staging area first, 2 (default) = two passes when the resident matrix exceeds 256 MB         */
+ *                          staging area first, 2 (default) = two passes when the resident matrix exceeds 256 MB
+ *   "candidate_tables"     1 (default): pqhip_codebook_create builds the per-cell candidate tables of the 1- / 2-float sub-vector
+ *                          encode kernel on the host (M = 150, K = 256: about 2.4 s on 8 cores, 34 ms at M = 10, K = 128 -- it pays
+ *                          for itself after some 5e8 / 2.6e8 encoded rows); 0: handles created from now on get no tables and
+ *                          encode on the kernels that evaluate every centroid (same codes)                                  */
 int32_t pqhip_ctx_set_option(pqhip_ctx *ctx, const char *name, int64_t value);
 /* Launch log of the calling thread: every kernel the library launches is noted by name; pqhip_launch_log() renders
  * "k_a + k_b x3 + ..." (distinct names in first-launch order with counts; valid until the thread's next call of

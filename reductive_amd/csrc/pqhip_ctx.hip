@@ -313,7 +313,8 @@ int32_t pqhip_ctx_set_option(pqhip_ctx* ctx, const char* name, int64_t value)
         {"kmeans_no_graph", &o.kmeans_no_graph},       {"opq_scratch_rows", &o.opq_scratch_rows},
         {"opq_fused", &o.opq_fused},                   {"opq_gather_rotation", &o.opq_gather_rotation},
         {"adc_single_query", &o.adc_single_query},     {"cross_product_exact", &o.cross_product_exact},
-        {"cross_product_group_bytes", &o.cross_product_group_bytes}, {"lookup_two_pass", &o.lookup_two_pass}};
+        {"cross_product_group_bytes", &o.cross_product_group_bytes}, {"lookup_two_pass", &o.lookup_two_pass},
+        {"candidate_tables", &o.candidate_tables}};
     for (auto& t : table)
         if (std::strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); return PQHIP_OK; }
     return PQHIP_EINVAL;

@@ -85,6 +85,7 @@ struct Options {
     std::atomic<int64_t> cross_product_exact{1};    // 0: X^T.R as a plain split-K product (float tolerance, no per-block partials)
     std::atomic<int64_t> lookup_two_pass{2};        // row lookups: 0 one pass, 1 select-then-reconstruct, 2 two passes when the matrix exceeds 256 MB
     std::atomic<int64_t> cross_product_group_bytes{0};   // workspace of partial matrices per launch group (0: 4 GiB; tests shrink it)
+    std::atomic<int64_t> candidate_tables{1};       // 0: Pq handles are created without the candidate tables of the 1- / 2-float encode kernel (vor2_prep.h)
 };
 
 struct Diag {

@@ -161,3 +161,27 @@ def test_ineligible_codebooks_and_kmeans_handles_use_the_other_kernels(ra):
     pq.set_encode_variant(11)
     with pytest.raises(Exception):
         pq.quantize_batch_device(torch.from_numpy(x).cuda())
+
+
+def test_handles_created_without_candidate_tables(ra):
+    """Context option "candidate_tables" = 0 (include/pqhip.h): no host table build at creation, the same codes from the kernels that
+    evaluate every centroid; handles created after the option is set back get their tables again."""
+    import torch
+    rng = np.random.default_rng(77)
+    q = rng.standard_normal((10, 128, 2)).astype(np.float32)
+    x = synth.normalish(78, (20_000, 20))
+    want = orc.quantize_batch(q, x, n_threads=8)
+    xd = torch.from_numpy(x).cuda()
+    ra.set_option("candidate_tables", 0)
+    try:
+        pq = ra.Pq(None, q)
+        assert pq.quantize_batch_device(xd).cpu().numpy().tobytes() == want.tobytes()
+        assert pq.last_encode_kernel() != "k_encode_vor2"
+        pq.set_encode_variant(11)                                  # asked for by name, no tables: refused like every forced variant that does not apply
+        with pytest.raises(Exception):
+            pq.quantize_batch_device(xd)
+    finally:
+        ra.set_option("candidate_tables", 1)
+    pq = ra.Pq(None, q)
+    assert pq.quantize_batch_device(xd).cpu().numpy().tobytes() == want.tobytes()
+    assert pq.last_encode_kernel() == "k_encode_vor2"
