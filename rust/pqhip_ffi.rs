@@ -338,6 +338,17 @@ pub fn set_cross_product_exact(exact: bool) -> bool {
     }
 }
 
+/// Candidate tables of the 1- / 2-float sub-vector encode kernel (include/pqhip.h, option "candidate_tables"): built on the host
+/// when the device image of a `Pq` is created -- about 0.9 s for M = 150, K = 256 on a GPU box's host, 8 ms for M = 10, K = 128 --
+/// and repaid only by some 1e8 encoded rows per codebook.  `false` makes images created from now on go without them (same codes
+/// from the kernels that evaluate every centroid): the setting for a caller that quantizes one vocabulary per codebook.
+pub fn set_candidate_tables(build: bool) -> bool {
+    match handles() {
+        Some(h) => unsafe { pqhip_ctx_set_option(h.ctx.0, b"candidate_tables\0".as_ptr() as *const c_char, build as i64) == PQHIP_OK },
+        None => false,
+    }
+}
+
 /// Instances kept in HBM for the length of an OPQ training run (`Opq::train_pq_using`, opq.rs:44-99):
 /// upload once, then one `train_step` per iteration replaces opq.rs:167-182 and the GEMM of :191.
 pub struct ResidentInstances { m: *mut pqhip_matrix, rows: usize, cols: usize }
